@@ -1,0 +1,230 @@
+/*
+ * ngp_hip.h -- C ABI of libngp_hip.so, the MI355X (gfx950) Instant-NGP rendering core.
+ *
+ * This is the drop-in boundary for the reference's four native extension
+ * modules (_raymarching, _gridencoder, _shencoder, _ffmlp).  The reference
+ * binds them with pybind11 over at::Tensor; here every entry point takes plain
+ * device pointers, sizes and a HIP stream, so the same library serves the
+ * Python packages under nerf-navigation_amd/ (ctypes), a C++ caller, or a
+ * pybind11 shim a reference maintainer might add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t (0 = the null stream);
+ *   - every function returns 0 on success, a negative NGP_E* code on bad
+ *     arguments / launch failure; ngp_last_error() returns the message of the
+ *     calling thread's last failure (the reference validates nothing in
+ *     raymarching and never checks a launch: raymarching.cu:15-18,152);
+ *   - outputs are caller-allocated, exactly as in the reference wrappers;
+ *     buffers the reference requires pre-zeroed are listed per function;
+ *   - no entry point allocates, frees or synchronises: all are capturable in
+ *     a hipGraph.
+ *   - dtype codes: NGP_F32 = 0, NGP_F16 = 1.
+ *
+ * Arithmetic contract (DESIGN.md "Numerics"): IEEE binary32, RNE, no FMA
+ * contraction in any kernel that feeds an integer decision; the reference's
+ * __expf is replaced by the deterministic ngp_expf of csrc/ngp_device.h.
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_OK 0
+#define NGP_EINVAL (-1)   /* bad argument (null pointer, unsupported D/C/width, size overflow) */
+#define NGP_ELAUNCH (-2)  /* hipGetLastError() reported a failure after the launch */
+#define NGP_EWORKSPACE (-3) /* workspace too small */
+
+#define NGP_F32 0
+#define NGP_F16 1
+
+int ngp_abi_version(void);
+const char* ngp_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* _raymarching  (reference: raymarching/src/raymarching.h:7-18)             */
+/* ------------------------------------------------------------------------ */
+
+/* raymarching.h:7  near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)
+ * rays_o, rays_d [N,3] f32; aabb [6] f32; nears, fars [N] f32. */
+int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                           float min_near, float* nears, float* fars, void* stream);
+
+/* raymarching.h:8  sph_from_ray(rays_o, rays_d, radius, N, coords) ; coords [N,2] f32 */
+int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream);
+
+/* raymarching.h:9  morton3D(coords, N, indices) ; coords [N,3] i32 -> indices [N] i32 */
+int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+
+/* raymarching.h:10 morton3D_invert(indices, N, coords) */
+int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+
+/* raymarching.h:11 packbits(grid, N, density_thresh, bitfield) ; grid [8N] f32 -> bitfield [N] u8 */
+int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream);
+
+/* raymarching.h:13 march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
+ *                                   nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
+ * xyzs, dirs [M,3], deltas [M,2] f32 PRE-ZEROED; rays [N,3] i32; counter [2] i32 (read-modify-write).
+ * Slot order is the deterministic one "ray 0, ray 1, ..." (a valid outcome of the
+ * reference's atomics, raymarching.cu:409-410).
+ * workspace: ngp_march_rays_train_workspace(N) bytes of scratch. */
+size_t ngp_march_rays_train_workspace(uint32_t N);
+int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                         int32_t* rays, int32_t* counter, uint32_t perturb,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* raymarching.h:14 composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
+int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                     uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image,
+                                     void* stream);
+
+/* raymarching.h:15 composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+ *                                                weights_sum, image, M, N, grad_sigmas, grad_rgbs)
+ * grad_sigmas [M], grad_rgbs [M,3] PRE-ZEROED. */
+int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                      const float* rgbs, const float* deltas, const int32_t* rays,
+                                      const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                      float* grad_sigmas, float* grad_rgbs, void* stream);
+
+/* raymarching.h:17 march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
+ *                             C, H, grid, nears, fars, xyzs, dirs, deltas, perturb)
+ * xyzs, dirs [>= n_alive*n_step, 3], deltas [.,2] PRE-ZEROED (zero delta = terminated, raymarching.cu:867). */
+int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                   float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream);
+
+/* raymarching.h:18 composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+ * mutates rays_alive (-1 = dead), rays_t, weights_sum, depth, image in place. */
+int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                       const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                       void* stream);
+
+/* Not in the reference's native surface: stable compaction of rays_alive (the reference does it with a torch
+ * boolean mask, nerf/renderer.py:365).  out [n_alive] i32, n_out [1] i32 device counter (overwritten).
+ * workspace: ngp_compact_alive_workspace(n_alive) bytes. */
+size_t ngp_compact_alive_workspace(uint32_t n_alive);
+int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* _gridencoder  (reference: gridencoder/src/gridencoder.h:12-13)            */
+/* ------------------------------------------------------------------------ */
+
+/* gridencoder.h:12 grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H,
+ *                                      calc_grad_inputs, dy_dx, gridtype, align_corners)
+ * inputs [B,D] f32 in [0,1]; embeddings [sO,C] `dtype`; offsets [L+1] i32 (device);
+ * outputs [L,B,C] `dtype` (level-major, as the reference); dy_dx [B, L*D*C] `dtype` (may be null if !calc).
+ * D in {2,3,4,5}, C in {1,2,4,8}, L <= 32; gridtype 0 = hash, 1 = tiled. */
+int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners,
+                            int dtype, void* stream);
+
+/* gridencoder.h:13 grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
+ *                                       calc_grad_inputs, dy_dx, grad_inputs, gridtype, align_corners)
+ * grad [L,B,C]; grad_embeddings [sO,C] PRE-ZEROED; grad_inputs [B,D] (all `dtype`). */
+int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                             int align_corners, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* _shencoder  (reference: shencoder/src/shencoder.h:10,13)                  */
+/* ------------------------------------------------------------------------ */
+
+/* shencoder.h:10 sh_encode_forward(inputs, outputs, B, D, C, calc_grad_inputs, dy_dx)
+ * inputs [B,3] f32; outputs [B,C*C] f32; dy_dx [B,3*C*C] f32 (may be null if !calc); C = degree in 1..8. */
+int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                          int calc_grad_inputs, float* dy_dx, void* stream);
+
+/* shencoder.h:13 sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs)
+ * grad_inputs [B,3] is accumulated into (+=), so PRE-ZEROED by the caller (shencoder.cu:379). */
+int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                           const float* dy_dx, float* grad_inputs, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* _ffmlp  (reference: ffmlp/src/ffmlp.h:8-14)                                */
+/* ------------------------------------------------------------------------ */
+
+/* ffmlp.h:8 ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+ *                         output_activation, forward_buffer, outputs)
+ * all tensors f16. inputs [B,input_dim]; weights flat [hidden,in] + (num_layers-1)*[hidden,hidden] + [output_dim,hidden];
+ * forward_buffer [num_layers,B,hidden]; outputs [B,output_dim]; output_dim == 16 (padded), hidden_dim == 64,
+ * input_dim in {16,32,48,64}; B % 16 == 0 (the Python wrapper pads to 128 like the reference).
+ * activation: 0 = ReLU (the only hidden activation reachable from the reference, ffmlp/ffmlp.py:107);
+ * output_activation: 6 = none. */
+int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                      void* forward_buffer, void* outputs, void* stream);
+
+/* ffmlp.h:9 ffmlp_inference(..., inference_buffer, outputs) ; inference_buffer is unused scratch (may be null) */
+int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                        void* inference_buffer, void* outputs, void* stream);
+
+/* ffmlp.h:11 ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
+ *                           activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
+ * grad [B,output_dim] f16; backward_buffer [num_layers,B,hidden] f16; grad_inputs [B,input_dim] f16;
+ * grad_weights flat f16 (same layout as weights).
+ * workspace: ngp_ffmlp_backward_workspace(...) bytes (f32 weight-gradient accumulators; zeroed by the call). */
+size_t ngp_ffmlp_backward_workspace(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers);
+int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer,
+                       uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                       uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
+                       void* grad_inputs, void* grad_weights, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ffmlp.h:13-14 allocate_splitk(size) / free_splitk(): the reference creates side streams for CUTLASS split-K
+ * GEMMs.  This implementation reduces weight gradients inside one kernel, so both are accepted no-ops. */
+int ngp_allocate_splitk(size_t size);
+int ngp_free_splitk(void);
+
+/* ------------------------------------------------------------------------ */
+/* Fused inference path (extra, opt-in; used by the package's own renderer)   */
+/* ------------------------------------------------------------------------ */
+
+/* Description of the field evaluated by the fused kernels: the network_ff model of the reference
+ * (nerf/network_ff.py:11-148): hash grid (D=3, C=2, L levels, f16 table) -> FFMLP(32->64->64->16) ->
+ * sigma = exp(h0), geo = h[1:16]; SH degree 4 (16) ++ geo (15) ++ 0 -> FFMLP(32->64->64->64->16) -> sigmoid. */
+typedef struct {
+    const void* embeddings;      /* [sO,2] f16 */
+    const int32_t* offsets;      /* [L+1] i32, device */
+    const void* sigma_weights;   /* flat f16, 64*(32+64+16)   = 7168  */
+    const void* color_weights;   /* flat f16, 64*(32+128+16)  = 11264 */
+    uint32_t L;                  /* 16 */
+    uint32_t H;                  /* base resolution (16) */
+    float S;                     /* log2(per_level_scale) */
+    float bound;                 /* world -> [0,1]: (x + bound) / (2 bound) */
+    float density_scale;         /* sigma multiplier (nerf/renderer.py:361) */
+} ngp_field_t;
+
+/* sigma/rgb for explicit points: the fused equivalent of NeRFNetwork.forward (nerf/network_ff.py:51-77) under
+ * autocast.  xyzs, dirs [M,3] f32; sigmas [M] f32 (already times density_scale); rgbs [M,3] f32. */
+int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
+                      float* sigmas, float* rgbs, void* stream);
+
+/* One whole frame of NeRFRenderer.run_cuda's inference branch (nerf/renderer.py:325-374) in one launch:
+ * near/far, occupancy march, field evaluation and compositing per ray, with no intermediate tensors.
+ * image [N,3], depth [N], weights_sum [N] f32 are fully written (no pre-zeroing needed);
+ * image already includes the background mix image + (1-ws)*bg_color and depth the (depth-near)/(far-near) map.
+ * stats [4] u32 device (zeroed by the call): [0] ray-samples evaluated, [1] rays that consumed > max_steps samples
+ * (schedule-dependent in the reference), [2] rays with at least one sample, [3] reserved.
+ * workspace: ngp_render_frame_workspace(N) bytes. */
+size_t ngp_render_frame_workspace(uint32_t N);
+int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
+                     const float* aabb, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                     float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                     float* image, float* depth, float* weights_sum, uint32_t* stats,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

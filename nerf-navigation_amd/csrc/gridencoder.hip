@@ -1,0 +1,363 @@
+// gridencoder.hip -- gfx950 kernels behind the `_gridencoder` native surface of the reference
+// (gridencoder/src/gridencoder.h:12-13): multi-resolution hash / tiled grid encoding, forward with optional
+// dy_dx, scatter-add backward into the table, and the input gradient from dy_dx.
+//
+// Layouts are the reference's: inputs [B,D] f32, table [sO,C], outputs [L,B,C] (level-major), dy_dx [B,L,D,C].
+// Roofline: HBM / Infinity-Cache gather bound -- 2^D * C * sizeof(T) table bytes per (sample, level), every one a
+// scattered access; all 2^D corner loads of a lane are issued before the first is consumed.
+//
+// Arithmetic is the reference's, operation for operation: positions and weights in binary32, accumulation in the
+// table dtype (c10::Half arithmetic = compute in float, round to half after every operation).
+#include "ngp_device.h"
+
+static constexpr uint32_t GE_MAX_LEVELS = 32;
+
+struct ge_levels {
+    float scale[GE_MAX_LEVELS];          // exp2f(level * S) * H - 1, evaluated on the host (gridencoder.cu:126)
+    uint32_t resolution[GE_MAX_LEVELS];  // ceil(scale) + 1                                 (gridencoder.cu:127)
+};
+
+static void ge_fill_levels(ge_levels& lv, uint32_t L, float S, uint32_t H) {
+    for (uint32_t l = 0; l < L; l++) {
+        lv.scale[l] = exp2f((float)l * S) * (float)H - 1.0f;
+        lv.resolution[l] = (uint32_t)ceilf(lv.scale[l]) + 1u;
+    }
+}
+
+// scalar_t arithmetic of the reference: float for float, round-to-half after every op for half
+template <typename T> struct ge_num;
+template <> struct ge_num<float> {
+    static __device__ __forceinline__ float rnd(float v) { return v; }
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct ge_num<_Float16> {
+    static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+    static __device__ __forceinline__ float load(const _Float16* p) { return (float)*p; }
+    static __device__ __forceinline__ void store(_Float16* p, float v) { *p = (_Float16)v; }
+};
+
+template <typename T, uint32_t C> struct alignas(sizeof(T) * C) ge_vec { T v[C]; };
+
+static __device__ __constant__ const uint32_t GE_PRIMES[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+
+template <uint32_t D>
+__device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
+                                             uint32_t resolution, const uint32_t (&pg)[D]) {
+    // reference get_grid_index / fast_hash: gridencoder.cu:35-72 (returns the row, not row*C)
+    uint32_t stride = 1, index = 0;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pg[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) {
+        uint32_t h = 0;
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) h ^= pg[d] * GE_PRIMES[d];
+        index = h;
+    }
+    return index % hashmap_size;
+}
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void k_grid_forward(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                      const int* __restrict__ offsets, T* __restrict__ outputs,
+                                                      uint32_t B, uint32_t L, ge_levels lv, bool calc_grad_inputs,
+                                                      T* __restrict__ dy_dx, uint32_t gridtype, bool align_corners) {
+    using num = ge_num<T>;
+    using vec = ge_vec<T, C>;
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+
+    const vec* tab = reinterpret_cast<const vec*>(grid) + (uint32_t)offsets[level];
+    const float* in = inputs + (uint64_t)b * D;
+    vec* out = reinterpret_cast<vec*>(outputs) + ((uint64_t)level * B + b);
+    T* dydx = dy_dx + ((uint64_t)b * L + level) * D * C;
+
+    float xin[D];
+    bool oob = false;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) { xin[d] = in[d]; oob |= (xin[d] < 0 || xin[d] > 1); }
+    if (oob) {                                        // gridencoder.cu:99-123
+        vec z;
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) z.v[ch] = (T)0.0f;
+        *out = z;
+        if (calc_grad_inputs) {
+            #pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) dydx[i] = (T)0.0f;
+        }
+        return;
+    }
+
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float pos[D];
+    uint32_t pg[D];
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = xin[d] * scale + (align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+
+    // issue all 2^D corner gathers, then blend in the reference's corner order
+    vec corner[1u << D];
+    float w[1u << D];
+    #pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wi = 1;
+        uint32_t pl[D];
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { wi *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { wi *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        w[idx] = wi;
+        corner[idx] = tab[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+    }
+    float res[C];
+    #pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.0f;
+    #pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) {
+            // scalar_t += float: the product narrows to scalar_t, then the sum rounds to scalar_t (gridencoder.cu:166)
+            const float prod = num::rnd(w[idx] * (float)corner[idx].v[ch]);
+            res[ch] = num::rnd(res[ch] + prod);
+        }
+    }
+    vec o;
+    #pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) o.v[ch] = (T)res[ch];
+    *out = o;
+
+    if (calc_grad_inputs) {                           // gridencoder.cu:180-223
+        #pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[C];
+            #pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0.0f;
+            #pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float wi = scale;
+                uint32_t pl[D];
+                #pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) { wi *= 1 - pos[d]; pl[d] = pg[d]; }
+                    else { wi *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                pl[gd] = pg[gd];
+                const vec left = tab[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+                pl[gd] = pg[gd] + 1;
+                const vec right = tab[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+                #pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float diff = num::rnd((float)right.v[ch] - (float)left.v[ch]);
+                    const float prod = num::rnd(wi * diff);
+                    rg[ch] = num::rnd(rg[ch] + prod);
+                }
+            }
+            #pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) dydx[gd * C + ch] = (T)rg[ch];
+        }
+    }
+}
+
+// scatter: one lane per (sample, pair of features, level)   (reference: gridencoder.cu:227-314)
+template <typename T, uint32_t D, uint32_t C, uint32_t N_C>
+__global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                       const int* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                       uint32_t B, uint32_t L, ge_levels lv, uint32_t gridtype, bool align_corners) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b = (uint32_t)(((uint64_t)tid * N_C) / C);
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t ch = tid * N_C - b * C;
+
+    T* gg = grad_grid + (uint64_t)(uint32_t)offsets[level] * C;
+    const float* in = inputs + (uint64_t)b * D;
+    const T* g = grad + ((uint64_t)level * B + b) * C + ch;
+
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float pos[D];
+    uint32_t pg[D];
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float x = in[d];
+        if (x < 0 || x > 1) return;                   // out of range: contributes nothing
+        pos[d] = x * scale + (align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    float gc[N_C];
+    #pragma unroll
+    for (uint32_t c = 0; c < N_C; c++) gc[c] = (float)g[c];
+
+    #pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wi = 1;
+        uint32_t pl[D];
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { wi *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { wi *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        const uint64_t row = (uint64_t)ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C + ch;
+        if constexpr (sizeof(T) == 2) {
+            static_assert(sizeof(T) != 2 || N_C == 2, "half scatter needs feature pairs");
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 v;
+            v.x = (_Float16)(wi * gc[0]);             // (__half)(w * grad) : gridencoder.cu:302
+            v.y = (_Float16)(wi * gc[1]);
+            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gg + row), v);
+        } else {
+            #pragma unroll
+            for (uint32_t c = 0; c < N_C; c++) unsafeAtomicAdd((float*)gg + row + c, wi * gc[c]);
+        }
+    }
+}
+
+// grad_inputs[b,d] = sum_{l,ch} grad[l,b,ch] * dy_dx[b,l,d,ch]   (reference: gridencoder.cu:317-343)
+template <typename T, uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx,
+                                                             T* __restrict__ grad_inputs, uint32_t B, uint32_t L) {
+    using num = ge_num<T>;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T* jac = dy_dx + (uint64_t)b * L * D * C;
+    float result = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        #pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const float prod = num::rnd((float)grad[((uint64_t)l * B + b) * C + ch] * (float)jac[(l * D + d) * C + ch]);
+            result = num::rnd(result + prod);
+        }
+    }
+    grad_inputs[t] = (T)result;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+
+template <typename T, uint32_t D, uint32_t C>
+static void ge_launch_forward(const float* inputs, const void* emb, const int* offsets, void* outputs, uint32_t B, uint32_t L,
+                              const ge_levels& lv, bool calc, void* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+    hipLaunchKernelGGL((k_grid_forward<T, D, C>), dim3(ngp_div_up(B, 256), L), dim3(256), 0, s,
+                       inputs, (const T*)emb, offsets, (T*)outputs, B, L, lv, calc, (T*)dy_dx, gridtype, ac);
+}
+
+template <typename T, uint32_t D>
+static int ge_forward_c(uint32_t C, const float* inputs, const void* emb, const int* offsets, void* outputs, uint32_t B, uint32_t L,
+                        const ge_levels& lv, bool calc, void* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+    switch (C) {
+        case 1: ge_launch_forward<T, D, 1>(inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s); return NGP_OK;
+        case 2: ge_launch_forward<T, D, 2>(inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s); return NGP_OK;
+        case 4: ge_launch_forward<T, D, 4>(inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s); return NGP_OK;
+        case 8: ge_launch_forward<T, D, 8>(inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s); return NGP_OK;
+        default: return ngp_fail(NGP_EINVAL, "GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+}
+
+template <typename T>
+static int ge_forward_d(uint32_t D, uint32_t C, const float* inputs, const void* emb, const int* offsets, void* outputs, uint32_t B,
+                        uint32_t L, const ge_levels& lv, bool calc, void* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+    switch (D) {
+        case 2: return ge_forward_c<T, 2>(C, inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s);
+        case 3: return ge_forward_c<T, 3>(C, inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s);
+        case 4: return ge_forward_c<T, 4>(C, inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s);
+        case 5: return ge_forward_c<T, 5>(C, inputs, emb, offsets, outputs, B, L, lv, calc, dy_dx, gridtype, ac, s);
+        default: return ngp_fail(NGP_EINVAL, "GridEncoding: D must be 2, 3, 4, or 5.");
+    }
+}
+
+extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                       int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners,
+                                       int dtype, void* stream) {
+    NGP_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
+    NGP_REQUIRE(!calc_grad_inputs || dy_dx, "grid_encode_forward: calc_grad_inputs needs dy_dx");
+    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_forward: L must be in 1..32");
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_forward: dtype must be f32 or f16");
+    NGP_REQUIRE((uint64_t)B * L * D * C < (1ull << 40), "grid_encode_forward: size overflow");
+    if (B == 0) return NGP_OK;
+    ge_levels lv;
+    ge_fill_levels(lv, L, S, H);
+    int rc = dtype == NGP_F32
+        ? ge_forward_d<float>(D, C, inputs, embeddings, offsets, outputs, B, L, lv, calc_grad_inputs != 0, dy_dx, gridtype, align_corners != 0, (hipStream_t)stream)
+        : ge_forward_d<_Float16>(D, C, inputs, embeddings, offsets, outputs, B, L, lv, calc_grad_inputs != 0, dy_dx, gridtype, align_corners != 0, (hipStream_t)stream);
+    if (rc != NGP_OK) return rc;
+    NGP_CHECK_LAUNCH("grid_encode_forward");
+    return NGP_OK;
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static void ge_launch_backward(const void* grad, const float* inputs, const int* offsets, void* gg, uint32_t B, uint32_t L,
+                               const ge_levels& lv, bool calc, const void* dy_dx, void* gi, uint32_t gridtype, bool ac, hipStream_t s) {
+    constexpr uint32_t N_C = C < 2 ? C : 2;           // features per lane (gridencoder.cu:380)
+    const uint32_t nthreads = (uint32_t)(((uint64_t)B * C) / N_C);
+    hipLaunchKernelGGL((k_grid_backward<T, D, C, N_C>), dim3(ngp_div_up(nthreads, 256), L), dim3(256), 0, s,
+                       (const T*)grad, inputs, offsets, (T*)gg, B, L, lv, gridtype, ac);
+    if (calc)
+        hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(ngp_div_up((uint64_t)B * D, 256)), dim3(256), 0, s,
+                           (const T*)grad, (const T*)dy_dx, (T*)gi, B, L);
+}
+
+template <typename T, uint32_t D>
+static int ge_backward_c(uint32_t C, const void* grad, const float* inputs, const int* offsets, void* gg, uint32_t B, uint32_t L,
+                         const ge_levels& lv, bool calc, const void* dy_dx, void* gi, uint32_t gridtype, bool ac, hipStream_t s) {
+    switch (C) {
+        case 1:
+            if constexpr (sizeof(T) == 2) return ngp_fail(NGP_EINVAL, "grid_encode_backward: f16 needs an even C (the reference forces f32 for odd C, grid.py:36-39)");
+            else { ge_launch_backward<T, D, 1>(grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s); return NGP_OK; }
+        case 2: ge_launch_backward<T, D, 2>(grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s); return NGP_OK;
+        case 4: ge_launch_backward<T, D, 4>(grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s); return NGP_OK;
+        case 8: ge_launch_backward<T, D, 8>(grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s); return NGP_OK;
+        default: return ngp_fail(NGP_EINVAL, "GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+}
+
+template <typename T>
+static int ge_backward_d(uint32_t D, uint32_t C, const void* grad, const float* inputs, const int* offsets, void* gg, uint32_t B, uint32_t L,
+                         const ge_levels& lv, bool calc, const void* dy_dx, void* gi, uint32_t gridtype, bool ac, hipStream_t s) {
+    switch (D) {
+        case 2: return ge_backward_c<T, 2>(C, grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s);
+        case 3: return ge_backward_c<T, 3>(C, grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s);
+        case 4: return ge_backward_c<T, 4>(C, grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s);
+        case 5: return ge_backward_c<T, 5>(C, grad, inputs, offsets, gg, B, L, lv, calc, dy_dx, gi, gridtype, ac, s);
+        default: return ngp_fail(NGP_EINVAL, "GridEncoding: D must be 2, 3, 4, or 5.");
+    }
+}
+
+extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                        void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                                        int align_corners, int dtype, void* stream) {
+    (void)embeddings;                                  // kept for signature parity; the scatter never reads the table
+    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
+    NGP_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs), "grid_encode_backward: calc_grad_inputs needs dy_dx and grad_inputs");
+    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_backward: L must be in 1..32");
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_backward: dtype must be f32 or f16");
+    if (B == 0) return NGP_OK;
+    ge_levels lv;
+    ge_fill_levels(lv, L, S, H);
+    int rc = dtype == NGP_F32
+        ? ge_backward_d<float>(D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, calc_grad_inputs != 0, dy_dx, grad_inputs, gridtype, align_corners != 0, (hipStream_t)stream)
+        : ge_backward_d<_Float16>(D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, calc_grad_inputs != 0, dy_dx, grad_inputs, gridtype, align_corners != 0, (hipStream_t)stream);
+    if (rc != NGP_OK) return rc;
+    NGP_CHECK_LAUNCH("grid_encode_backward");
+    return NGP_OK;
+}

@@ -1,0 +1,188 @@
+// ngp_device.h -- device/host helpers shared by the gfx950 kernels of libngp_hip.so.
+//
+// gfx950 only: wave = 64 lanes, no portability macros.  Everything here is
+// compiled with -ffp-contract=off: the march/composite/encoder arithmetic must
+// round exactly as written (DESIGN.md "Numerics").
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ngp_hip.h"
+
+// ---------------------------------------------------------------------------
+// host: error reporting
+// ---------------------------------------------------------------------------
+
+extern thread_local char ngp_err_buf[512];
+
+static inline int ngp_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ngp_err_buf, sizeof(ngp_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define NGP_REQUIRE(cond, ...) \
+    do { if (!(cond)) return ngp_fail(NGP_EINVAL, __VA_ARGS__); } while (0)
+
+#define NGP_CHECK_LAUNCH(name) \
+    do { hipError_t e_ = hipGetLastError(); \
+         if (e_ != hipSuccess) return ngp_fail(NGP_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+static inline uint32_t ngp_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// device: scalar helpers
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float ngp_clampf(float x, float lo, float hi) {
+    return fminf(hi, fmaxf(lo, x));                 // reference clamp(): raymarching.cu:36-38
+}
+
+// Deterministic exp standing in for the reference's __expf (raymarching.cu:547,650,869): identical, operation
+// for operation, to o_expf() of the oracle.  Two-term Cody-Waite reduction and a degree-7 Horner chain, all fmaf.
+__device__ __forceinline__ float ngp_expf(float x) {
+    if (!(x >= -87.0f)) return (x != x) ? x : 0.0f;
+    if (x > 88.0f) return __builtin_inff();
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723e-06f, r);
+    float p = 1.0f / 5040.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return __int_as_float(__float_as_int(p) + (((int)n) << 23));
+}
+
+// 10-bit-per-axis Morton interleave (reference: raymarching.cu:58-83)
+__device__ __forceinline__ uint32_t ngp_spread3(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t ngp_morton3(uint32_t x, uint32_t y, uint32_t z) {
+    return ngp_spread3(x) | (ngp_spread3(y) << 1) | (ngp_spread3(z) << 2);
+}
+__device__ __forceinline__ uint32_t ngp_compact3(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// PCG-XSH-RR 64/32 with Brown's jump-ahead (reference: raymarching/src/pcg32.h:44-205)
+struct ngp_pcg32 {
+    uint64_t state, inc;
+    static constexpr uint64_t MULT = 0x5851f42d4c957f2dULL;
+    __host__ __device__ uint32_t next_uint() {
+        const uint64_t s = state;
+        state = s * MULT + inc;
+        const uint32_t xs = (uint32_t)(((s >> 18u) ^ s) >> 27u);
+        const uint32_t rot = (uint32_t)(s >> 59u);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+    }
+    __host__ __device__ void seed(uint64_t initstate, uint64_t initseq = 1u) {
+        state = 0u;
+        inc = (initseq << 1u) | 1u;
+        next_uint();
+        state += initstate;
+        next_uint();
+    }
+    __host__ __device__ void advance(uint64_t delta) {
+        uint64_t cm = MULT, cp = inc, am = 1u, ap = 0u;
+        while (delta > 0) {
+            if (delta & 1u) { am *= cm; ap = ap * cm + cp; }
+            cp = (cm + 1u) * cp;
+            cm *= cm;
+            delta >>= 1;
+        }
+        state = am * state + ap;
+    }
+    __device__ float next_float() {
+        return __uint_as_float((next_uint() >> 9) | 0x3f800000u) - 1.0f;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// device: the occupancy march step shared by march_rays_train, march_rays and the fused renderer
+// (reference: raymarching.cu:363-404, 431-483, 759-813)
+// ---------------------------------------------------------------------------
+
+#define NGP_SKIP_GUARD 65536   // bound on the empty-space substep loop (the reference's is unbounded: :400-402)
+
+struct ngp_march_t {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
+    const uint8_t* grid;
+
+    __device__ __forceinline__ void setup(const float* o, const float* d, float bound_, float dt_gamma_,
+                                          uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid_) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
+        bound = bound_; dt_gamma = dt_gamma_;
+        Hf = (float)H; Cf = (float)C; Hm1 = (float)(H - 1);
+        rH = 1.0f / Hf;
+        H3 = (float)(H * H * H);
+        dt_min = (2.0f * 1.7320508075688772f) / (float)max_steps;
+        dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (C - 1))) / Hf;
+        grid = grid_;
+    }
+
+    __device__ __forceinline__ int mip(int e) const {
+        return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e));
+    }
+
+    // Probe at parameter t.  Occupied: returns true with the sample (x,y,z,dt), t untouched.
+    // Empty: returns false after moving t past the cell (DDA to the exit face, then dt substeps).
+    __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt) const {
+        const float tc = t;
+        x = ngp_clampf(ox + tc * dx, -bound, bound);
+        y = ngp_clampf(oy + tc * dy, -bound, bound);
+        z = ngp_clampf(oz + tc * dz, -bound, bound);
+        dt = ngp_clampf(tc * dt_gamma, dt_min, dt_max);
+
+        int e_pos, e_dt;
+        (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
+        (void)frexpf((dt * Hf) * 0.5f, &e_dt);          // *0.5 is exact, so float == the reference's double product
+        const int lp = mip(e_pos), ld = mip(e_dt);
+        const int level = lp > ld ? lp : ld;
+
+        const float mip_bound = fminf((float)(1 << level), bound);
+        const float mip_rbound = 1.0f / mip_bound;
+
+        // reference :378-380 evaluates 0.5*(..)*H in double; halving is exact, so one float rounding is identical
+        const int nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * Hf, 0.0f, Hm1);
+        const int ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * Hf, 0.0f, Hm1);
+        const int nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * Hf, 0.0f, Hm1);
+
+        const uint32_t index = (uint32_t)((float)level * H3 + (float)ngp_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const bool occ = (grid[index >> 3] >> (index & 7u)) & 1u;
+        if (occ) return true;
+
+        const float tx = (((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH) * 2.0f - 1.0f) * mip_bound - x) * rdx;
+        const float ty = (((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH) * 2.0f - 1.0f) * mip_bound - y) * rdy;
+        const float tz = (((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH) * 2.0f - 1.0f) * mip_bound - z) * rdz;
+        const float tt = tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        float tn = tc;
+        int guard = 0;
+        do {
+            tn += ngp_clampf(tn * dt_gamma, dt_min, dt_max);
+        } while (tn < tt && ++guard < NGP_SKIP_GUARD);
+        t = tn;
+        return false;
+    }
+};

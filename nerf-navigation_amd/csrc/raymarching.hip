@@ -1,0 +1,576 @@
+// raymarching.hip -- gfx950 kernels behind the `_raymarching` native surface of the reference
+// (raymarching/src/raymarching.h:7-18): AABB slab test, Morton codes, bit packing, the occupancy-grid
+// ray marcher (training and inference form) and the alpha compositors.
+//
+// One lane per ray.  A wave holds 64 rays; blocks are 256 threads (4 waves) so that a launch of N rays needs
+// N/256 workgroups -- >= 2500 for an 800x800 frame, enough to fill 256 CUs several times over.  The occupancy
+// bitfield (cascade * 128^3 / 8 = 0.5 MB at bound 2) is L2-resident; the kernels are bound by the divergent
+// per-ray loops, not by HBM.
+#include "ngp_device.h"
+
+thread_local char ngp_err_buf[512] = {0};
+
+extern "C" int ngp_abi_version(void) { return 1; }
+extern "C" const char* ngp_last_error(void) { return ngp_err_buf; }
+
+static constexpr uint32_t RM_BLOCK = 256;
+
+// ---------------------------------------------------------------------------
+// near / far
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void ngp_near_far(const float* o, const float* d, const float* aabb, float min_near,
+                                             float& near, float& far) {
+    // reference: raymarching.cu:109-146
+    const float rdx = 1.0f / d[0], rdy = 1.0f / d[1], rdz = 1.0f / d[2];
+    float tn = (aabb[0] - o[0]) * rdx, tf = (aabb[3] - o[0]) * rdx;
+    if (tn > tf) { const float s = tn; tn = tf; tf = s; }
+    float yn = (aabb[1] - o[1]) * rdy, yf = (aabb[4] - o[1]) * rdy;
+    if (yn > yf) { const float s = yn; yn = yf; yf = s; }
+    if (tn > yf || yn > tf) { near = far = 3.402823466e+38f; return; }
+    if (yn > tn) tn = yn;
+    if (yf < tf) tf = yf;
+    float zn = (aabb[2] - o[2]) * rdz, zf = (aabb[5] - o[2]) * rdz;
+    if (zn > zf) { const float s = zn; zn = zf; zf = s; }
+    if (tn > zf || zn > tf) { near = far = 3.402823466e+38f; return; }
+    if (zn > tn) tn = zn;
+    if (zf < tf) tf = zf;
+    if (tn < min_near) tn = min_near;
+    near = tn; far = tf;
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const float* __restrict__ aabb, uint32_t N, float min_near,
+                                                       float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    float bb[6];
+    #pragma unroll
+    for (int i = 0; i < 6; i++) bb[i] = aabb[i];
+    float near, far;
+    ngp_near_far(rays_o + 3ull * n, rays_d + 3ull * n, bb, min_near, near, far);
+    nears[n] = near;
+    fars[n] = far;
+}
+
+extern "C" int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                                      float min_near, float* nears, float* fars, void* stream) {
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_near_far, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       rays_o, rays_d, aabb, N, min_near, nears, fars);
+    NGP_CHECK_LAUNCH("near_far_from_aabb");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// background sphere coordinates (cold path: only with bg_radius > 0)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RM_BLOCK) void k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                           float radius, uint32_t N, float* __restrict__ coords) {
+    // reference: raymarching.cu:165-200
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3ull * n], oy = rays_o[3ull * n + 1], oz = rays_o[3ull * n + 2];
+    const float dx = rays_d[3ull * n], dy = rays_d[3ull * n + 1], dz = rays_d[3ull * n + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = ox * dx + oy * dy + oz * dz;
+    const float C = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * C)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);
+    const float phi = atan2f(z, x);
+    const float RPI = 0.3183098861837907f;
+    coords[2ull * n] = 2 * theta * RPI - 1;
+    coords[2ull * n + 1] = phi * RPI;
+}
+
+extern "C" int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    NGP_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       rays_o, rays_d, radius, N, coords);
+    NGP_CHECK_LAUNCH("sph_from_ray");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Morton codes, bit packing
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RM_BLOCK) void k_morton3D(const int* __restrict__ coords, uint32_t N, int* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int)ngp_morton3((uint32_t)coords[3ull * n], (uint32_t)coords[3ull * n + 1], (uint32_t)coords[3ull * n + 2]);
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_morton3D_invert(const int* __restrict__ indices, uint32_t N, int* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const int ind = indices[n];                      // signed shifts, as the reference (raymarching.cu:251-255)
+    coords[3ull * n + 0] = (int)ngp_compact3((uint32_t)(ind >> 0));
+    coords[3ull * n + 1] = (int)ngp_compact3((uint32_t)(ind >> 1));
+    coords[3ull * n + 2] = (int)ngp_compact3((uint32_t)(ind >> 2));
+}
+
+// One lane packs one byte from 8 consecutive floats: two 16-byte loads per lane, fully coalesced across the wave.
+__global__ __launch_bounds__(RM_BLOCK) void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
+                                                       uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4*>(grid)[2ull * n];
+    const float4 b = reinterpret_cast<const float4*>(grid)[2ull * n + 1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+extern "C" int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
+    NGP_REQUIRE(coords && indices, "morton3D: null pointer");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_morton3D, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, coords, N, indices);
+    NGP_CHECK_LAUNCH("morton3D");
+    return NGP_OK;
+}
+
+extern "C" int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
+    NGP_REQUIRE(coords && indices, "morton3D_invert: null pointer");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_morton3D_invert, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, indices, N, coords);
+    NGP_CHECK_LAUNCH("morton3D_invert");
+    return NGP_OK;
+}
+
+extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
+    NGP_REQUIRE(grid && bitfield, "packbits: null pointer");
+    NGP_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15u) == 0, "packbits: grid must be 16-byte aligned");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_packbits, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, grid, N, density_thresh, bitfield);
+    NGP_CHECK_LAUNCH("packbits");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// training march: count -> scan -> write  (reference does both passes in one kernel with atomics,
+// raymarching.cu:314-484; the prefix sum makes slot order deterministic: ray_index = n)
+// ---------------------------------------------------------------------------
+
+struct march_args {
+    const float* rays_o; const float* rays_d; const uint8_t* grid;
+    const float* nears; const float* fars;
+    float bound, dt_gamma;
+    uint32_t max_steps, N, C, H, M, perturb;
+};
+
+__device__ __forceinline__ float train_t0(const ngp_march_t& m, float near, uint32_t n, uint32_t perturb) {
+    if (!perturb) return near;
+    ngp_pcg32 rng; rng.seed(42u);                    // hard-coded seed of the reference (raymarching.cu:489)
+    rng.advance((uint64_t)n);
+    return near + m.dt_min * rng.next_float();
+}
+
+// block-wide inclusive scan of one uint per thread (4 waves): wave scan by DPP-free shuffles, then wave totals in LDS
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* lds4, uint32_t& block_total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t s = v;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(s, off, 64);
+        if ((int)lane >= off) s += up;
+    }
+    if (lane == 63u) lds4[wave] = s;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    #pragma unroll
+    for (uint32_t w = 0; w < RM_BLOCK / 64; w++) {
+        const uint32_t t = lds4[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    __syncthreads();
+    block_total = total;
+    return s + base;
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_march_train_count(march_args a, int* __restrict__ rays,
+                                                                const int* __restrict__ counter,
+                                                                uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    uint32_t num_steps = 0;
+    if (n < a.N) {
+        ngp_march_t m;
+        m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+        const float far = a.fars[n];
+        float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
+        while (t < far && num_steps < a.max_steps) {
+            if (m.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+        }
+        const uint32_t slot = (uint32_t)counter[1] + n;
+        if (slot < a.N) rays[3ull * slot + 2] = (int)num_steps;      // stash; the write pass completes the record
+    }
+    uint32_t total;
+    (void)block_inclusive_scan(num_steps, lds4, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of the per-block totals, then bump the two counters
+__global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks,
+                                                               int* __restrict__ counter, uint32_t N,
+                                                               uint32_t* __restrict__ bases /* [2]: point base, ray base */) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = (uint32_t)counter[0];
+    __syncthreads();
+    const uint32_t start = carry;
+    for (uint32_t i0 = 0; i0 < nblocks; i0 += RM_BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_inclusive_scan(v, lds4, total);
+        const uint32_t c = carry;
+        if (i < nblocks) block_sums[i] = c + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bases[0] = start;
+        bases[1] = (uint32_t)counter[1];
+        counter[0] = (int)carry;
+        counter[1] = (int)((uint32_t)counter[1] + N);
+    }
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_march_train_write(march_args a, int* __restrict__ rays,
+                                                                const uint32_t* __restrict__ block_sums,
+                                                                const uint32_t* __restrict__ bases,
+                                                                float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                float* __restrict__ deltas) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t ray_base = bases[1];
+    const uint32_t slot = ray_base + n;
+    const bool live = (n < a.N) && (slot < a.N);
+    const uint32_t num_steps = live ? (uint32_t)rays[3ull * slot + 2] : 0u;
+    uint32_t total;
+    const uint32_t inc = block_inclusive_scan(num_steps, lds4, total);
+    if (!live) return;
+    const uint32_t point_index = block_sums[blockIdx.x] + inc - num_steps;
+    rays[3ull * slot] = (int)n;
+    rays[3ull * slot + 1] = (int)point_index;
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= a.M) return;      // dropped ray (reference :420)
+
+    ngp_march_t m;
+    m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+    const float far = a.fars[n];
+    float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
+    float last_t = t;
+    uint32_t step = 0;
+    float* px = xyzs + 3ull * point_index;
+    float* pd = dirs + 3ull * point_index;
+    float* pl = deltas + 2ull * point_index;
+    while (t < far && step < num_steps) {
+        if (m.probe(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        }
+    }
+}
+
+extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) {
+    return sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_BLOCK) + 4);
+}
+
+extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                    int32_t* rays, int32_t* counter, uint32_t perturb,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter, "march_rays_train: null pointer");
+    NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays_train: bad C/H/max_steps");
+    NGP_REQUIRE(workspace && workspace_bytes >= ngp_march_rays_train_workspace(N), "march_rays_train: workspace too small");
+    if (N == 0) return NGP_OK;
+    const uint32_t nblocks = ngp_div_up(N, RM_BLOCK);
+    uint32_t* block_sums = (uint32_t*)workspace;
+    uint32_t* bases = block_sums + nblocks;
+    march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, N, C, H, M, perturb};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, a, rays, counter, block_sums);
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
+    hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas);
+    NGP_CHECK_LAUNCH("march_rays_train");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// training composite
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RM_BLOCK) void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                  const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                  uint32_t M, uint32_t N, float* __restrict__ weights_sum,
+                                                                  float* __restrict__ depth, float* __restrict__ image) {
+    // reference: raymarching.cu:506-582
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        weights_sum[index] = 0; depth[index] = 0;
+        image[3ull * index] = 0; image[3ull * index + 1] = 0; image[3ull * index + 2] = 0;
+        return;
+    }
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3ull * offset;
+    const float* dl = deltas + 2ull * offset;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    for (uint32_t k = 0; k < num_steps; k++) {
+        const float alpha = 1.0f - ngp_expf(-s[0] * dl[0]);
+        const float w = alpha * T;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        t += dl[1];
+        d += w * t;
+        ws += w;
+        T *= 1.0f - alpha;
+        if (T < 1e-4f) break;
+        s++; c += 3; dl += 2;
+    }
+    weights_sum[index] = ws; depth[index] = d;
+    image[3ull * index] = r; image[3ull * index + 1] = g; image[3ull * index + 2] = b;
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+                                                                  const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                  const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                  const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                  uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
+                                                                  float* __restrict__ grad_rgbs) {
+    // reference: raymarching.cu:607-688
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float g0 = grad_image[3ull * index], g1 = grad_image[3ull * index + 1], g2 = grad_image[3ull * index + 2];
+    const float rf = image[3ull * index], gf = image[3ull * index + 1], bf = image[3ull * index + 2], wsf = weights_sum[index];
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3ull * offset;
+    const float* dl = deltas + 2ull * offset;
+    float* gs = grad_sigmas + offset;
+    float* gc = grad_rgbs + 3ull * offset;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    for (uint32_t k = 0; k < num_steps; k++) {
+        const float alpha = 1.0f - ngp_expf(-s[0] * dl[0]);
+        const float w = alpha * T;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        T *= 1.0f - alpha;
+        if (T < 1e-4f) break;
+        gc[0] = g0 * w; gc[1] = g1 * w; gc[2] = g2 * w;
+        gs[0] = dl[0] * (g0 * (T * c[0] - (rf - r)) +
+                         g1 * (T * c[1] - (gf - g)) +
+                         g2 * (T * c[2] - (bf - b)) +
+                         gws * (1.0f - wsf));
+        s++; c += 3; dl += 2; gs++; gc += 3;
+    }
+}
+
+extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                                uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image, void* stream) {
+    NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null sample pointer");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    NGP_CHECK_LAUNCH("composite_rays_train_forward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                                 const float* rgbs, const float* deltas, const int32_t* rays,
+                                                 const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                                 float* grad_sigmas, float* grad_rgbs, void* stream) {
+    NGP_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, "composite_rays_train_backward: null pointer");
+    NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), "composite_rays_train_backward: null sample pointer");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    NGP_CHECK_LAUNCH("composite_rays_train_backward");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// inference march / composite
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RM_BLOCK) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+                                                         const float* __restrict__ rays_t, march_args a,
+                                                         float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
+    // reference: raymarching.cu:707-814
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    ngp_march_t m;
+    m.setup(a.rays_o + 3ll * index, a.rays_d + 3ll * index, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+    float* px = xyzs + 3ull * n * n_step;
+    float* pd = dirs + 3ull * n * n_step;
+    float* pl = deltas + 2ull * n * n_step;
+    float t = rays_t[index];
+    const float far = a.fars[index];
+    if (a.perturb) {                                  // seed = perturb, jump = alive SLOT (reference :752-755,819)
+        ngp_pcg32 rng; rng.seed((uint64_t)a.perturb);
+        rng.advance((uint64_t)n);
+        t += m.dt_min * rng.next_float();
+    }
+    float last_t = t, x, y, z, dt;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        if (m.probe(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_composite_rays(uint32_t n_alive, uint32_t n_step, int* __restrict__ rays_alive,
+                                                             float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                                             const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                             float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                             float* __restrict__ image) {
+    // reference: raymarching.cu:829-913
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float* s = sigmas + (uint64_t)n * n_step;
+    const float* c = rgbs + 3ull * n * n_step;
+    const float* dl = deltas + 2ull * n * n_step;
+    float t = rays_t[index];
+    float ws = weights_sum[index], d = depth[index];
+    float r = image[3ll * index], g = image[3ll * index + 1], b = image[3ll * index + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - ngp_expf(-s[0] * dl[0]);
+        const float T = 1 - ws;
+        const float w = alpha * T;
+        ws += w;
+        t += dl[1];
+        d += w * t;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        if ((double)T < 1e-4) break;                  // double literal in the reference (:890)
+        s++; c += 3; dl += 2; step++;
+    }
+    if (step < n_step) rays_alive[n] = -1;
+    else rays_t[index] = t;
+    weights_sum[index] = ws; depth[index] = d;
+    image[3ll * index] = r; image[3ll * index + 1] = g; image[3ll * index + 2] = b;
+}
+
+extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                              const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                              uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                              float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
+    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas, "march_rays: null pointer");
+    NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
+    if (n_alive == 0 || n_step == 0) return NGP_OK;
+    march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, 0u, C, H, 0u, perturb};
+    hipLaunchKernelGGL(k_march_rays, dim3(ngp_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    NGP_CHECK_LAUNCH("march_rays");
+    return NGP_OK;
+}
+
+extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                                  const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
+    NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "composite_rays: null pointer");
+    if (n_alive == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_composite_rays, dim3(ngp_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    NGP_CHECK_LAUNCH("composite_rays");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stable compaction of the alive list (rays_alive[rays_alive >= 0], nerf/renderer.py:365) without a host sync:
+// wave ballot + popcount for the in-wave rank, block scan for the block rank, a scanned table of block totals
+// for the global rank.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RM_BLOCK) void k_compact_count(const int* __restrict__ rays_alive, uint32_t n_alive,
+                                                            uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const bool keep = (n < n_alive) && (rays_alive[n] >= 0);
+    const unsigned long long mask = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_compact_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks, int* __restrict__ n_out) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < nblocks; i0 += RM_BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_inclusive_scan(v, lds4, total);
+        const uint32_t c = carry;
+        if (i < nblocks) block_sums[i] = c + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_out[0] = (int)carry;
+}
+
+__global__ __launch_bounds__(RM_BLOCK) void k_compact_write(const int* __restrict__ rays_alive, uint32_t n_alive,
+                                                            const uint32_t* __restrict__ block_sums, int* __restrict__ out) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const int v = (n < n_alive) ? rays_alive[n] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) lds4[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = block_sums[blockIdx.x];
+    for (uint32_t w = 0; w < wave; w++) base += lds4[w];
+    if (keep) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+}
+
+extern "C" size_t ngp_compact_alive_workspace(uint32_t n_alive) {
+    return sizeof(uint32_t) * ((size_t)ngp_div_up(n_alive ? n_alive : 1, RM_BLOCK) + 4);
+}
+
+extern "C" int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(rays_alive && out && n_out, "compact_alive: null pointer");
+    NGP_REQUIRE(workspace && workspace_bytes >= ngp_compact_alive_workspace(n_alive), "compact_alive: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nblocks = ngp_div_up(n_alive ? n_alive : 1, RM_BLOCK);
+    uint32_t* block_sums = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, n_out);
+    hipLaunchKernelGGL(k_compact_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums, out);
+    NGP_CHECK_LAUNCH("compact_alive");
+    return NGP_OK;
+}

@@ -1,0 +1,140 @@
+"""Drop-in `gridencoder` package: `_grid_encode` / `GridEncoder` of the reference's gridencoder/grid.py, backed by
+libngp_hip.so (csrc/gridencoder.hip).
+
+Same surface as the reference: argument order and defaults, the autocast rule (half table only when autocast is on
+and C is even, grid.py:36-39), level-major kernel output permuted back to [B, L*C] (grid.py:42,52), dy_dx saved only
+when the inputs require grad, a dense zero-initialised grad_embeddings per backward (grid.py:74), state_dict keys
+`embeddings` and `offsets`.  As in the reference, `backward` calls a non-differentiable native op, so the gradient
+w.r.t. the inputs is a constant under create_graph=True (the pose filter's Hessian relies on this).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+import ngp_hip as _hip
+
+_gridtype_to_id = {"hash": 0, "tiled": 1}
+
+
+class _grid_encode(Function):
+    """reference: gridencoder/grid.py:19-87"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False):
+        _hip.require_cuda(inputs, embeddings, offsets)
+        inputs = inputs.contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = np.log2(per_level_scale)       # float64 here, narrowed to float at the C boundary like the reference
+        H = base_resolution
+
+        if torch.is_autocast_enabled() and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        embeddings = embeddings.contiguous()
+        if inputs.dtype != torch.float32:
+            raise RuntimeError("inputs must be a float32 tensor")
+
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
+        if calc_grad_inputs:
+            dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype)
+        else:
+            dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)
+
+        _hip.check(_hip.lib().ngp_grid_encode_forward(_hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets), _hip.ptr(outputs),
+                                                      B, D, C, L, float(S), H, int(calc_grad_inputs), _hip.ptr(dy_dx),
+                                                      gridtype, int(align_corners), _hip.dtype_code(embeddings.dtype),
+                                                      _hip.stream()), "grid_encode_forward")
+
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, H, gridtype]
+        ctx.calc_grad_inputs = calc_grad_inputs
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype = ctx.dims
+        calc_grad_inputs = ctx.calc_grad_inputs
+
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)
+        grad_embeddings = torch.zeros_like(embeddings)
+        if calc_grad_inputs:
+            grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
+        else:
+            grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
+
+        _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
+                                                       _hip.ptr(grad_embeddings), B, D, C, L, float(S), H, int(calc_grad_inputs),
+                                                       _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
+                                                       _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")
+
+        if calc_grad_inputs:
+            return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
+        return None, grad_embeddings, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    """reference: gridencoder/grid.py:93-156"""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype="hash", align_corners=False):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.align_corners = align_corners
+
+        # level table: rows per level = min(2^log2_hashmap_size, (res [+1])^D) rounded up to 8 (grid.py:113-123)
+        offsets, offset = [], 0
+        self.max_params = 2 ** log2_hashmap_size
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
+                f"align_corners={self.align_corners}")
+
+    def forward(self, inputs, bound=1):
+        inputs = (inputs + bound) / (2 * bound)       # [-bound, bound] -> [0, 1]
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners)
+        return outputs.view(prefix_shape + [self.output_dim])

@@ -1,0 +1,128 @@
+"""ctypes binding of libngp_hip.so (include/ngp_hip.h) for torch tensors.
+
+This is plumbing only: torch supplies device memory and the current HIP stream, every kernel lives in the
+shared library.  There is NO fallback: if the library is missing or a call fails this module raises, so a GPU
+test can never pass on a silent CPU/eager path.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libngp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, F16 = 0, 1
+
+c_u32, c_f32, c_int, c_vp, c_sz = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ngp_hip.h one to one
+_SIGNATURES = {
+    "ngp_abi_version": (c_int, []),
+    "ngp_last_error": (ctypes.c_char_p, []),
+    "ngp_near_far_from_aabb": (c_int, [c_vp, c_vp, c_vp, c_u32, c_f32, c_vp, c_vp, c_vp]),
+    "ngp_sph_from_ray": (c_int, [c_vp, c_vp, c_f32, c_u32, c_vp, c_vp]),
+    "ngp_morton3D": (c_int, [c_vp, c_u32, c_vp, c_vp]),
+    "ngp_morton3D_invert": (c_int, [c_vp, c_u32, c_vp, c_vp]),
+    "ngp_packbits": (c_int, [c_vp, c_u32, c_f32, c_vp, c_vp]),
+    "ngp_march_rays_train_workspace": (c_sz, [c_u32]),
+    "ngp_march_rays_train": (c_int, [c_vp, c_vp, c_vp, c_f32, c_f32, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp,
+                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_sz, c_vp]),
+    "ngp_composite_rays_train_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp]),
+    "ngp_composite_rays_train_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_march_rays": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
+                               c_vp, c_vp, c_vp, c_u32, c_vp]),
+    "ngp_composite_rays": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ngp_compact_alive_workspace": (c_sz, [c_u32]),
+    "ngp_compact_alive": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_grid_encode_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_int, c_vp,
+                                        c_u32, c_int, c_int, c_vp]),
+    "ngp_grid_encode_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_int,
+                                         c_vp, c_vp, c_u32, c_int, c_int, c_vp]),
+    "ngp_sh_encode_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_int, c_vp, c_vp]),
+    "ngp_sh_encode_backward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_ffmlp_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_ffmlp_inference": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_ffmlp_backward_workspace": (c_sz, [c_u32, c_u32, c_u32, c_u32]),
+    "ngp_ffmlp_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_int,
+                                   c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_allocate_splitk": (c_int, [c_sz]),
+    "ngp_free_splitk": (c_int, []),
+    "ngp_field_forward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_render_frame_workspace": (c_sz, [c_u32]),
+    "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+class ngp_field_t(ctypes.Structure):
+    """include/ngp_hip.h: ngp_field_t"""
+    _fields_ = [("embeddings", c_vp), ("offsets", c_vp), ("sigma_weights", c_vp), ("color_weights", c_vp),
+                ("L", c_u32), ("H", c_u32), ("S", c_f32), ("bound", c_f32), ("density_scale", c_f32)]
+
+
+def build(verbose=False):
+    """Compile libngp_hip.so for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j", "8"], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ngp_last_error().decode(errors="replace")
+        raise RuntimeError(f"libngp_hip {what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    """The HIP stream torch is currently enqueueing on (the reference used the legacy default stream)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libngp_hip: expected a tensor on the GPU (there is no CPU path)")
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.float16:
+        return F16
+    raise RuntimeError(f"libngp_hip: unsupported dtype {dt} (float32 / float16 only)")
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

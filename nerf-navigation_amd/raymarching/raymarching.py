@@ -1,0 +1,250 @@
+"""Drop-in `raymarching` package: the autograd Functions of the reference's raymarching/raymarching.py, backed
+by libngp_hip.so (csrc/raymarching.hip) instead of the `_raymarching` CUDA extension.
+
+Same names, argument order, defaults, dtype casts (float32 via custom_fwd), return values and in-place
+behaviour as the reference (file:line cited per function).  Differences, all supersets:
+  * kernels run on torch's current HIP stream (the reference used the legacy default stream);
+  * march_rays_train allocates slots in ray order (deterministic) instead of atomic arrival order.
+"""
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+import ngp_hip as _hip
+
+__all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
+           "composite_rays_train", "march_rays", "composite_rays", "compact_alive"]
+
+
+def _rays(t):
+    """[..., 3] -> contiguous [N, 3] on the GPU (the reference moves CPU inputs over: raymarching.py:34-35)."""
+    if not t.is_cuda:
+        t = t.cuda()
+    return t.contiguous().view(-1, 3)
+
+
+class _near_far_from_aabb(Function):
+    """reference: raymarching/raymarching.py:19-49"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        aabb = aabb.to(rays_o.device).contiguous()
+        N = rays_o.shape[0]
+        nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        _hip.check(_hip.lib().ngp_near_far_from_aabb(_hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(aabb), N, min_near,
+                                                     _hip.ptr(nears), _hip.ptr(fars), _hip.stream()), "near_far_from_aabb")
+        return nears, fars
+
+
+near_far_from_aabb = _near_far_from_aabb.apply
+
+
+class _sph_from_ray(Function):
+    """reference: raymarching/raymarching.py:52-80"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, radius):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        N = rays_o.shape[0]
+        coords = torch.empty(N, 2, dtype=rays_o.dtype, device=rays_o.device)
+        _hip.check(_hip.lib().ngp_sph_from_ray(_hip.ptr(rays_o), _hip.ptr(rays_d), radius, N, _hip.ptr(coords), _hip.stream()),
+                   "sph_from_ray")
+        return coords
+
+
+sph_from_ray = _sph_from_ray.apply
+
+
+class _morton3D(Function):
+    """reference: raymarching/raymarching.py:83-102"""
+
+    @staticmethod
+    def forward(ctx, coords):
+        if not coords.is_cuda:
+            coords = coords.cuda()
+        N = coords.shape[0]
+        indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+        c = coords.int().contiguous()
+        _hip.check(_hip.lib().ngp_morton3D(_hip.ptr(c), N, _hip.ptr(indices), _hip.stream()), "morton3D")
+        return indices
+
+
+morton3D = _morton3D.apply
+
+
+class _morton3D_invert(Function):
+    """reference: raymarching/raymarching.py:106-124"""
+
+    @staticmethod
+    def forward(ctx, indices):
+        if not indices.is_cuda:
+            indices = indices.cuda()
+        N = indices.shape[0]
+        coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+        i = indices.int().contiguous()
+        _hip.check(_hip.lib().ngp_morton3D_invert(_hip.ptr(i), N, _hip.ptr(coords), _hip.stream()), "morton3D_invert")
+        return coords
+
+
+morton3D_invert = _morton3D_invert.apply
+
+
+class _packbits(Function):
+    """reference: raymarching/raymarching.py:129-153 (writes into `bitfield` when given)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, grid, thresh, bitfield=None):
+        if not grid.is_cuda:
+            grid = grid.cuda()
+        grid = grid.contiguous()
+        C, H3 = grid.shape[0], grid.shape[1]
+        N = C * H3 // 8
+        if bitfield is None:
+            bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+        _hip.check(_hip.lib().ngp_packbits(_hip.ptr(grid), N, thresh, _hip.ptr(bitfield), _hip.stream()), "packbits")
+        return bitfield
+
+
+packbits = _packbits.apply
+
+
+class _march_rays_train(Function):
+    """reference: raymarching/raymarching.py:161-228 (same M / mean_count / align logic, same D2H read of the counter)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        if not density_bitfield.is_cuda:
+            density_bitfield = density_bitfield.cuda()
+        density_bitfield = density_bitfield.contiguous()
+        dev = rays_o.device
+
+        N = rays_o.shape[0]
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            if align > 0:
+                mean_count += align - mean_count % align
+            M = mean_count
+
+        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+
+        L = _hip.lib()
+        ws = _hip.workspace(L.ngp_march_rays_train_workspace(N), dev)
+        _hip.check(L.ngp_march_rays_train(_hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), bound, dt_gamma,
+                                          max_steps, N, C, H, M, _hip.ptr(nears.contiguous()), _hip.ptr(fars.contiguous()),
+                                          _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays),
+                                          _hip.ptr(step_counter), int(perturb), _hip.ptr(ws), ws.numel(), _hip.stream()),
+                   "march_rays_train")
+
+        if force_all_rays or mean_count <= 0:
+            m = step_counter[0].item()
+            if align > 0:
+                m += align - m % align
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        return xyzs, dirs, deltas, rays
+
+
+march_rays_train = _march_rays_train.apply
+
+
+class _composite_rays_train(Function):
+    """reference: raymarching/raymarching.py:233-283 (grad_depth ignored: :270)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigmas, rgbs, deltas, rays):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+        _hip.check(_hip.lib().ngp_composite_rays_train_forward(_hip.ptr(sigmas), _hip.ptr(rgbs), _hip.ptr(deltas), _hip.ptr(rays),
+                                                               M, N, _hip.ptr(weights_sum), _hip.ptr(depth), _hip.ptr(image),
+                                                               _hip.stream()), "composite_rays_train_forward")
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        ctx.dims = [M, N]
+        return weights_sum, depth, image
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        grad_weights_sum = grad_weights_sum.contiguous()
+        grad_image = grad_image.contiguous()
+        sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+        M, N = ctx.dims
+        grad_sigmas = torch.zeros_like(sigmas)
+        grad_rgbs = torch.zeros_like(rgbs)
+        _hip.check(_hip.lib().ngp_composite_rays_train_backward(_hip.ptr(grad_weights_sum), _hip.ptr(grad_image), _hip.ptr(sigmas),
+                                                                _hip.ptr(rgbs), _hip.ptr(deltas), _hip.ptr(rays),
+                                                                _hip.ptr(weights_sum), _hip.ptr(image), M, N,
+                                                                _hip.ptr(grad_sigmas), _hip.ptr(grad_rgbs), _hip.stream()),
+                   "composite_rays_train_backward")
+        return grad_sigmas, grad_rgbs, None, None
+
+
+composite_rays_train = _composite_rays_train.apply
+
+
+class _march_rays(Function):
+    """reference: raymarching/raymarching.py:292-335 (M padded past the next multiple of `align`)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
+                align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        M = n_alive * n_step
+        if align > 0:
+            M += align - (M % align)
+        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=rays_o.device)
+        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=rays_o.device)
+        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=rays_o.device)
+        _hip.check(_hip.lib().ngp_march_rays(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t), _hip.ptr(rays_o),
+                                             _hip.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _hip.ptr(density_bitfield),
+                                             _hip.ptr(near), _hip.ptr(far), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas),
+                                             int(perturb), _hip.stream()), "march_rays")
+        return xyzs, dirs, deltas
+
+
+march_rays = _march_rays.apply
+
+
+class _composite_rays(Function):
+    """reference: raymarching/raymarching.py:340-359 (returns an empty tuple; mutates its arguments in place)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+        _hip.check(_hip.lib().ngp_composite_rays(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t),
+                                                 _hip.ptr(sigmas.contiguous()), _hip.ptr(rgbs.contiguous()), _hip.ptr(deltas),
+                                                 _hip.ptr(weights_sum), _hip.ptr(depth), _hip.ptr(image), _hip.stream()),
+                   "composite_rays")
+        return tuple()
+
+
+composite_rays = _composite_rays.apply
+
+
+def compact_alive(rays_alive, n_alive=None):
+    """Stable compaction `rays_alive[rays_alive >= 0]` (nerf/renderer.py:365) done on the device.
+    Returns (compacted [n_alive] int32, count [1] int32 device tensor); only the first count entries are valid."""
+    n = rays_alive.shape[0] if n_alive is None else n_alive
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=rays_alive.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
+    L = _hip.lib()
+    ws = _hip.workspace(L.ngp_compact_alive_workspace(n), rays_alive.device)
+    _hip.check(L.ngp_compact_alive(_hip.ptr(rays_alive), n, _hip.ptr(out), _hip.ptr(cnt), _hip.ptr(ws), ws.numel(), _hip.stream()),
+               "compact_alive")
+    return out, cnt

@@ -1,0 +1,40 @@
+"""Shared synthetic inputs for the tests (seeded, small enough for the CPU oracle)."""
+import numpy as np
+
+
+def blob_bitfield(oracle, cascade=2, H=128, seed=0, n_blobs=40, bound=2.0):
+    """Occupancy bitfield [cascade*H^3/8] from random spheres; Morton-ordered cells like the reference's density grid."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(H ** 3, dtype=np.int32)
+    coords = oracle.morton3D_invert(idx).astype(np.float32)           # cell (x,y,z) of each Morton index
+    grid = np.zeros((cascade, H ** 3), np.float32)
+    for cas in range(cascade):
+        b = min(2.0 ** cas, bound)
+        centres = ((coords + 0.5) / H * 2 - 1) * b
+        c = rng.uniform(-0.8 * b, 0.8 * b, size=(n_blobs, 3)).astype(np.float32)
+        r = rng.uniform(0.05 * b, 0.25 * b, size=n_blobs).astype(np.float32)
+        for k in range(n_blobs):
+            d2 = ((centres - c[k]) ** 2).sum(1)
+            grid[cas, d2 < r[k] ** 2] = 1.0
+    return oracle.packbits(grid, 0.5), grid
+
+
+def camera_rays(n_side=32, radius=3.0, seed=0, jitter=True):
+    """Pinhole rays from a camera on an orbit looking at the origin; a few degenerate directions appended."""
+    rng = np.random.default_rng(seed)
+    th = rng.uniform(0, 2 * np.pi)
+    eye = np.array([radius * np.cos(th), radius * np.sin(th), 0.7 * radius * 0.3], np.float32)
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0, 0, 1], np.float32)
+    right = np.cross(fwd, up); right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    u, v = np.meshgrid(np.linspace(-0.6, 0.6, n_side), np.linspace(-0.6, 0.6, n_side))
+    d = fwd[None] + u.reshape(-1, 1) * right[None] + v.reshape(-1, 1) * up[None]
+    if jitter:
+        d += rng.normal(scale=1e-3, size=d.shape)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = np.broadcast_to(eye, d.shape).astype(np.float32).copy()
+    # axis-parallel rays (a zero component in d: 1/d = inf) and a ray that misses the box
+    extra_o = np.array([[-3, 0.1, 0.2], [0.3, -3, 0.1], [0.2, 0.1, 3], [5, 5, 5]], np.float32)
+    extra_d = np.array([[1, 0, 0], [0, 1, 0], [0, 0, -1], [1, 0, 0]], np.float32)
+    return np.concatenate([o, extra_o]), np.concatenate([d, extra_d])

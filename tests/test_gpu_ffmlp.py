@@ -1,0 +1,86 @@
+"""GPU parity for the fused MLP (v_mfma_f32_16x16x32_f16) against the CPU oracle.
+ * exact-integer data proves the MFMA fragment maps and the permuted-k weight layout (every product and sum is exactly
+   representable, so any misplaced element changes the result);
+ * random half data: tolerance.  The reference accumulates in half inside WMMA, the oracle in double, the kernel in
+   binary32 inside the MFMA, each rounding the layer output to half once: results may differ by one half ulp after a
+   layer, which later layers amplify -- bound stated below."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def run_hip(dev, x, w, input_dim, num_layers, save):
+    import ngp_hip
+    B = x.shape[0]
+    out = torch.empty(B, 16, dtype=torch.float16, device=dev)
+    fb = torch.empty(num_layers, B, 64, dtype=torch.float16, device=dev) if save else None
+    L = ngp_hip.lib()
+    fn = L.ngp_ffmlp_forward if save else L.ngp_ffmlp_inference
+    ngp_hip.check(fn(ngp_hip.ptr(t(x, dev)), ngp_hip.ptr(t(w, dev)), B, input_dim, 16, 64, num_layers, 0, 6, ngp_hip.ptr(fb),
+                     ngp_hip.ptr(out), ngp_hip.stream()))
+    return out.cpu().numpy(), (fb.cpu().numpy() if save else None)
+
+
+@pytest.mark.parametrize("input_dim,num_layers", [(32, 2), (32, 3), (64, 2), (16, 2), (48, 3), (32, 4)])
+def test_ffmlp_exact_integer_data(oracle, dev, input_dim, num_layers):
+    rng = np.random.default_rng(input_dim * 10 + num_layers)
+    B = 16 * 37
+    nw = oracle.ffmlp_num_params(input_dim, 16, 64, num_layers)
+    # weights in {-1, 0, 1} (sparse), inputs small non-negative integers: all activations stay small integers, exact in half
+    w = rng.choice([-1.0, 0.0, 0.0, 0.0, 1.0], size=nw).astype(np.float16)
+    x = rng.integers(0, 3, size=(B, input_dim)).astype(np.float16)
+    ref, fb_ref = oracle.ffmlp_forward(x, w, input_dim, 16, 64, num_layers, save=True)
+    assert np.abs(ref.astype(np.float32)).max() < 2048 and np.abs(ref.astype(np.float32)).max() > 3
+    got, fb = run_hip(dev, x, w, input_dim, num_layers, True)
+    assert np.array_equal(fb.view(np.uint16), fb_ref.view(np.uint16)), "forward_buffer"
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), "outputs"
+    got_inf, _ = run_hip(dev, x, w, input_dim, num_layers, False)
+    assert np.array_equal(got_inf.view(np.uint16), ref.view(np.uint16)), "inference outputs"
+
+
+@pytest.mark.parametrize("input_dim,num_layers", [(32, 2), (32, 3)])
+def test_ffmlp_random_data_tolerance(oracle, dev, input_dim, num_layers):
+    rng = np.random.default_rng(1)
+    B = 128 * 9
+    nw = oracle.ffmlp_num_params(input_dim, 16, 64, num_layers)
+    std = np.sqrt(3 / 64)
+    w = rng.uniform(-std, std, size=nw).astype(np.float16)
+    x = rng.normal(size=(B, input_dim)).astype(np.float16)
+    ref, fb_ref = oracle.ffmlp_forward(x, w, input_dim, 16, 64, num_layers, save=True)
+    got, fb = run_hip(dev, x, w, input_dim, num_layers, True)
+    # first hidden layer: same exact products, sums differ only in accumulation order => at most 1 half ulp
+    a, b = fb[0].astype(np.float32), fb_ref[0].astype(np.float32)
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 2.0 ** -10)) <= 2.0 ** -10
+    # outputs: a half ulp per layer amplified by |W| <= sqrt(3/64) rows of 64
+    scale = np.abs(ref.astype(np.float32)).max()
+    assert np.max(np.abs(got.astype(np.float32) - ref.astype(np.float32))) <= 4e-3 * scale
+    # most outputs agree to the bit
+    assert (got.view(np.uint16) == ref.view(np.uint16)).mean() > 0.9
+
+
+def test_ffmlp_module_pads_like_reference(oracle, dev):
+    from ffmlp import FFMLP
+    net = FFMLP(32, 16, 64, 2).to(dev).eval()
+    w = net.weights.detach().cpu().numpy().astype(np.float16)
+    for B in (100, 128, 1000):
+        x = np.random.default_rng(B).normal(size=(B, 32)).astype(np.float32)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            y = net(t(x, dev))
+        assert y.shape == (B, 16) and y.dtype == torch.float16
+        ref, _ = oracle.ffmlp_forward(x.astype(np.float16), w, 32, 16, 64, 2)
+        assert np.max(np.abs(y.cpu().numpy().astype(np.float32) - ref.astype(np.float32))) <= 4e-3 * np.abs(ref.astype(np.float32)).max()
+    with pytest.raises(RuntimeError):                      # without autocast the inputs are float: rejected like CHECK_IS_HALF
+        net(t(x, dev))
+
+
+def test_ffmlp_rejects_unsupported(dev):
+    import ngp_hip
+    z = torch.zeros(4096, dtype=torch.float16, device=dev)
+    rc = ngp_hip.lib().ngp_ffmlp_inference(ngp_hip.ptr(z), ngp_hip.ptr(z), 16, 32, 16, 128, 2, 0, 6, None, ngp_hip.ptr(z), ngp_hip.stream())
+    assert rc == -1 and b"hidden_dim" in ngp_hip.lib().ngp_last_error()

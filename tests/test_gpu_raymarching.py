@@ -1,0 +1,247 @@
+"""GPU parity: every `raymarching` op through the drop-in package (ctypes -> C ABI -> gfx950 kernels) against the
+CPU oracle on the same seeded inputs.  Integer/index results and all march/composite float results are BIT-EXACT
+(the oracle and the kernels share one arithmetic contract: no FMA contraction, the deterministic exp)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import blob_bitfield, camera_rays
+
+pytestmark = pytest.mark.gpu
+
+BOUND, CAS, H = 2.0, 2, 128
+AABB = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def bits(a):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else a.dtype)
+
+
+def assert_same_bits(got, want, what):
+    g, w = bits(got), bits(want)
+    assert g.shape == w.shape, f"{what}: shape {g.shape} vs {w.shape}"
+    bad = np.flatnonzero(g.reshape(-1) != w.reshape(-1))
+    assert bad.size == 0, f"{what}: {bad.size} of {g.size} words differ, first at {bad[:5]}"
+
+
+@pytest.fixture(scope="module")
+def scene(oracle):
+    bitfield, _ = blob_bitfield(oracle, CAS, H, seed=1, bound=BOUND)
+    o, d = camera_rays(48, radius=3.2, seed=2)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    return dict(bitfield=bitfield, o=o, d=d, nears=nears, fars=fars)
+
+
+def test_near_far_from_aabb(oracle, dev):
+    import raymarching
+    o, d = camera_rays(64, radius=3.0, seed=5)
+    rng = np.random.default_rng(0)
+    o2 = rng.uniform(-4, 4, size=(5000, 3)).astype(np.float32)       # origins inside and outside the box
+    d2 = rng.normal(size=(5000, 3)).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    for min_near in (0.2, 0.0):
+        n_ref, f_ref = oracle.near_far_from_aabb(o, d, AABB, min_near)
+        n, f = raymarching.near_far_from_aabb(t(o, dev), t(d, dev), t(AABB, dev), min_near)
+        assert_same_bits(n, n_ref, "nears")
+        assert_same_bits(f, f_ref, "fars")
+    assert (n_ref == np.finfo(np.float32).max).any(), "test must include rays that miss the box"
+
+
+def test_near_far_accepts_cpu_inputs_like_reference(oracle, dev):
+    import raymarching
+    o, d = camera_rays(8, seed=1)
+    n, f = raymarching.near_far_from_aabb(torch.from_numpy(o), torch.from_numpy(d), t(AABB, dev), 0.2)
+    assert n.is_cuda and n.shape == (o.shape[0],)
+
+
+def test_sph_from_ray(oracle, dev):
+    import raymarching
+    rng = np.random.default_rng(0)
+    o = rng.uniform(-1, 1, size=(4096, 3)).astype(np.float32)
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = raymarching.sph_from_ray(t(o, dev), t(d, dev), 4.0).cpu().numpy()
+    ref = oracle.sph_from_ray(o, d, 4.0)
+    # sqrtf/atan2f come from different libms (ocml vs glibc): tolerance, not bits.  phi wraps at +-1.
+    dphi = np.abs(got[:, 1] - ref[:, 1]); dphi = np.minimum(dphi, 2 - dphi)
+    assert np.max(np.abs(got[:, 0] - ref[:, 0])) < 2e-6 and dphi.max() < 2e-6
+
+
+def test_morton_roundtrip_and_oracle(oracle, dev):
+    import raymarching
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 1024, size=(100000, 3)).astype(np.int32)
+    idx = raymarching.morton3D(t(c, dev))
+    assert_same_bits(idx, oracle.morton3D(c), "morton3D")
+    back = raymarching.morton3D_invert(idx)
+    assert_same_bits(back, c, "morton3D_invert(morton3D(c))")
+    # the full 128^3 lattice, as update_extra_state sweeps it (nerf/renderer.py:471)
+    i = np.arange(128 ** 3, dtype=np.int32)
+    assert_same_bits(raymarching.morton3D_invert(t(i, dev)), oracle.morton3D_invert(i), "morton3D_invert lattice")
+    assert raymarching.morton3D(t(c[:0], dev)).shape == (0,)
+
+
+def test_packbits(oracle, dev):
+    import raymarching
+    rng = np.random.default_rng(0)
+    grid = rng.uniform(-1, 30, size=(CAS, H ** 3)).astype(np.float32)
+    grid[0, :64] = 10.0                                  # values equal to the threshold are NOT set (strict >)
+    grid[1, 100:200] = -1.0                              # untrained cells
+    ref = oracle.packbits(grid, 10.0)
+    assert np.array_equal(ref, np.packbits(grid.reshape(-1) > 10.0, bitorder="little"))
+    got = raymarching.packbits(t(grid, dev), 10.0)
+    assert_same_bits(got, ref, "packbits")
+    buf = torch.zeros(CAS * H ** 3 // 8, dtype=torch.uint8, device=dev)
+    out = raymarching.packbits(t(grid, dev), 10.0, buf)
+    assert out.data_ptr() == buf.data_ptr()              # written in place when a bitfield is given
+    assert_same_bits(buf, ref, "packbits in place")
+
+
+@pytest.mark.parametrize("perturb", [0, 7])
+@pytest.mark.parametrize("n_step", [1, 4, 8])
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
+def test_march_rays_bit_exact(oracle, dev, scene, perturb, n_step, dt_gamma):
+    import raymarching
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    N = o.shape[0]
+    rng = np.random.default_rng(3)
+    alive = rng.permutation(N)[: N - 37].astype(np.int32)            # a shuffled subset, like a compacted list
+    rays_t = nears.copy()
+    rays_t[::3] += 0.37                                               # rays resumed mid-way
+    x_ref, d_ref, l_ref = oracle.march_rays(alive.size, n_step, alive, rays_t, o, d, BOUND, bf, CAS, H, nears, fars,
+                                            128, perturb, dt_gamma, 1024)
+    x, dd, l = raymarching.march_rays(alive.size, n_step, t(alive, dev), t(rays_t, dev), t(o, dev), t(d, dev), BOUND,
+                                      t(bf, dev), CAS, H, t(nears, dev), t(fars, dev), 128, perturb, dt_gamma, 1024)
+    assert x.shape[0] % 128 == 0 and x.shape[0] > alive.size * n_step - 1
+    assert_same_bits(l, l_ref, "deltas")
+    assert_same_bits(x, x_ref, "xyzs")
+    assert_same_bits(dd, d_ref, "dirs")
+    assert (l_ref[:, 0] > 0).sum() > 1000, "scene must produce samples"
+
+
+def test_march_then_composite_loop_bit_exact(oracle, dev, scene):
+    """The whole run_cuda inference loop (nerf/renderer.py:343-369) with a synthetic field: alive sets, rays_t and
+    the accumulators must match the oracle bit for bit at every iteration."""
+    import raymarching
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    N = o.shape[0]
+
+    def field(xyz):                                                   # a cheap analytic sigma/rgb, float32 on the host
+        s = (40.0 * np.exp(-4.0 * (xyz ** 2).sum(1))).astype(np.float32)
+        c = (0.5 + 0.5 * np.sin(3.0 * xyz)).astype(np.float32)
+        return s, c
+
+    ws_r, dp_r, im_r = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive_r, t_r = np.arange(N, dtype=np.int32), nears.copy()
+    ws, dp, im = t(ws_r, dev), t(dp_r, dev), t(im_r, dev)
+    alive, rt = t(alive_r, dev), t(t_r, dev)
+    to, td, tb, tn, tf = t(o, dev), t(d, dev), t(bf, dev), t(nears, dev), t(fars, dev)
+    step, iters = 0, 0
+    while step < 1024:
+        n_alive = alive_r.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        x_r, _, l_r = oracle.march_rays(n_alive, n_step, alive_r, t_r, o, d, BOUND, bf, CAS, H, nears, fars, 128, False, 0.0, 1024)
+        s_r, c_r = field(x_r)
+        oracle.composite_rays(n_alive, n_step, alive_r, t_r, s_r, c_r, l_r, ws_r, dp_r, im_r)
+
+        x, _, l = raymarching.march_rays(n_alive, n_step, alive, rt, to, td, BOUND, tb, CAS, H, tn, tf, 128, False, 0.0, 1024)
+        assert_same_bits(x, x_r, f"xyzs it{iters}")
+        raymarching.composite_rays(n_alive, n_step, alive, rt, t(s_r, dev), t(c_r, dev), l, ws, dp, im)
+        assert_same_bits(alive, alive_r, f"rays_alive it{iters}")
+        assert_same_bits(rt, t_r, f"rays_t it{iters}")
+
+        packed, cnt = raymarching.compact_alive(alive)
+        alive_r = alive_r[alive_r >= 0]
+        assert int(cnt.item()) == alive_r.shape[0]
+        alive = packed[: alive_r.shape[0]].contiguous()
+        assert_same_bits(alive, alive_r, f"compacted it{iters}")
+        step += n_step
+        iters += 1
+    assert iters > 5
+    assert_same_bits(ws, ws_r, "weights_sum")
+    assert_same_bits(dp, dp_r, "depth")
+    assert_same_bits(im, im_r, "image")
+    assert ws_r.max() > 0.9, "some rays must saturate (exercises the T < 1e-4 exit)"
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("mode", ["first_epoch", "mean_count", "force_all"])
+def test_march_rays_train_bit_exact(oracle, dev, scene, perturb, mode):
+    import raymarching
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    kw = dict(perturb=perturb, align=128, dt_gamma=0.0, max_steps=1024)
+    if mode == "first_epoch":
+        kw.update(mean_count=-1, force_all_rays=False)
+    elif mode == "mean_count":
+        kw.update(mean_count=20000, force_all_rays=False)            # deliberately too small: later rays are dropped
+    else:
+        kw.update(mean_count=20000, force_all_rays=True)
+    c_ref = np.zeros(2, np.int32)
+    x_r, d_r, l_r, r_r = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, c_ref, **kw)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    x, dd, l, r = raymarching.march_rays_train(t(o, dev), t(d, dev), BOUND, t(bf, dev), CAS, H, t(nears, dev), t(fars, dev),
+                                               cnt, kw["mean_count"], perturb, 128, kw["force_all_rays"], 0.0, 1024)
+    assert_same_bits(cnt, c_ref, "counter")
+    assert_same_bits(r, r_r, "rays")
+    assert_same_bits(l, l_r, "deltas")
+    assert_same_bits(x, x_r, "xyzs")
+    assert_same_bits(dd, d_r, "dirs")
+    if mode == "mean_count":
+        assert (r_r[:, 1] + r_r[:, 2] >= x_r.shape[0]).any(), "test must include dropped rays"
+
+
+def test_march_rays_train_matches_iterated_march_rays(oracle, scene):
+    """SURVEY 8(c) relation 8 (oracle self-consistency, CPU only but kept beside its GPU siblings): marching to
+    completion emits the same samples per ray as march_rays_train(force_all_rays, perturb=False)."""
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    o, d, nears, fars = o[:400], d[:400], nears[:400], fars[:400]
+    x_r, _, l_r, rays = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, None, -1, False, -1, True, 0.0, 1024)
+    for n in range(0, 400, 13):
+        off, cnt = rays[n, 1], rays[n, 2]
+        alive = np.array([n], np.int32)
+        x1, _, l1 = oracle.march_rays(1, 1024, alive, nears.copy(), o, d, BOUND, bf, CAS, H, nears, fars, -1, False, 0.0, 1024)
+        k = int((l1[:, 0] > 0).sum())
+        assert k == cnt
+        assert np.array_equal(x1[:k].view(np.uint32), x_r[off:off + cnt].view(np.uint32))
+
+
+def test_composite_rays_train_forward_backward(oracle, dev, scene):
+    import raymarching
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    x, _, l, rays = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, None, 30000, True, 128, False, 0.0, 1024)
+    rng = np.random.default_rng(0)
+    M = x.shape[0]
+    sig = (50.0 * np.exp(-3.0 * (x ** 2).sum(1)) * rng.uniform(0.5, 1.5, M)).astype(np.float32)
+    rgb = rng.uniform(0, 1, size=(M, 3)).astype(np.float32)
+    ws_r, dp_r, im_r = oracle.composite_rays_train_forward(sig, rgb, l, rays)
+
+    ts, tc = t(sig, dev).requires_grad_(True), t(rgb, dev).requires_grad_(True)
+    ws, dp, im = raymarching.composite_rays_train(ts, tc, t(l, dev), t(rays, dev))
+    assert_same_bits(ws, ws_r, "weights_sum")
+    assert_same_bits(dp, dp_r, "depth")
+    assert_same_bits(im, im_r, "image")
+    assert (rays[:, 1] + rays[:, 2] >= M).any() and (rays[:, 2] == 0).any()     # dropped and empty rays present
+
+    g_ws = rng.normal(size=ws_r.shape).astype(np.float32)
+    g_im = rng.normal(size=im_r.shape).astype(np.float32)
+    gs_r, gc_r = oracle.composite_rays_train_backward(g_ws, g_im, sig, rgb, l, rays, ws_r, im_r)
+    # grad_depth is ignored by the reference (raymarching.py:270): feed a non-zero one and expect no effect
+    torch.autograd.backward([ws, dp, im], [t(g_ws, dev), torch.ones_like(dp), t(g_im, dev)])
+    assert_same_bits(ts.grad, gs_r, "grad_sigmas")
+    assert_same_bits(tc.grad, gc_r, "grad_rgbs")
+
+
+def test_empty_inputs(dev):
+    import raymarching
+    z3 = torch.zeros(0, 3, device=dev)
+    n, f = raymarching.near_far_from_aabb(z3, z3, t(AABB, dev), 0.2)
+    assert n.shape == (0,) and f.shape == (0,)
+    out, cnt = raymarching.compact_alive(torch.full((5,), -1, dtype=torch.int32, device=dev))
+    assert int(cnt.item()) == 0
