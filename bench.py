@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ray-samples/s of 800x800 novel-view renders of the synthetic Stonehenge stand-in
+("S-ring", SURVEY.md 8d / BASELINE config 2) through the fused gfx950 path (csrc/render_fused.hip).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+one rank per GPU.  A step = one frame = ONE kernel launch over 640,000 rays already resident in HBM.  Rays shard
+embarrassingly: every rank renders its own stream of camera poses with a replica of the model (25 MB half table +
+36 KB of weights + 0.5 MB bitfield) and there is no collective on the data path -> weak scaling; the only
+collectives are the timing barrier and the reduction of the counters.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the render kernel against HBM with the algorithmic gather bytes
+(512 B per ray-sample); `cpu_baseline` is the CPU oracle (a port: the reference has no CPU path) on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GATHER_BYTES_PER_SAMPLE = 512          # 16 levels x 8 corners x 2 features x 2 B
+MLP_FLOPS_PER_SAMPLE = 2 * (64 * (32 + 64 + 16) + 64 * (32 + 128 + 16))   # FFMLP shapes of nerf/network_ff.py
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--cpu-res", type=int, default=96, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--path", default="fused", choices=["fused", "per_op"], help="per_op = the reference-shaped op-by-op loop")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    importlib.import_module("nerf-navigation_amd")
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+
+    model = W.make_model(0)
+    grid = W.density_grid()
+    field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(model)
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
+    ren.load_density_grid(grid)
+
+    H = Wd = args.res
+    intr = W.intrinsics(H, Wd)
+    n_poses = 8
+    # every rank walks the same orbit, phase-shifted by its rank, so ranks never render the same view at the same step
+    rays = []
+    for k in range(n_poses):
+        o, d = W.get_rays(W.orbit_pose((k * world + rank) % (n_poses * world), n_poses * world), intr, H, Wd)
+        rays.append((torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]))
+    N = H * Wd
+
+    def frame(k):
+        o, d = rays[k % n_poses]
+        if args.path == "fused":
+            return ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        frame(k)
+    sync_all()
+
+    stats = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        out = frame(k)
+        ev[k][1].record()
+        if args.path == "fused":
+            stats.append(out["stats"])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    if args.path == "fused":
+        samples = int(torch.stack(stats)[:, 0].to(torch.int64).sum().item())
+        capped = int(torch.stack(stats)[:, 1].to(torch.int64).sum().item())
+    else:
+        # op-by-op loop: count with one extra fused pass per pose (same per-ray sample sequence)
+        per_pose = [int(ren.render_fused(*rays[k], bg_color=1)["stats"][0].item()) for k in range(n_poses)]
+        samples = sum(per_pose[k % n_poses] for k in range(args.steps))
+        capped = 0
+
+    tot = torch.tensor([float(samples), elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        t_max = tot[1:2].clone()
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        s_sum = tot[0:1].clone()
+        dist.all_reduce(s_sum, op=dist.ReduceOp.SUM)
+        elapsed_max, samples_all = float(t_max.item()), float(s_sum.item())
+    else:
+        elapsed_max, samples_all = elapsed, float(samples)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = samples_all / elapsed_max
+    ms_per_step = 1e3 * elapsed_max / args.steps
+    avg_kernel_s = 1e-3 * float(np.mean(kernel_ms))
+    samples_per_launch = samples / args.steps
+    achieved = GATHER_BYTES_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e9
+    result = {
+        "metric": "ray-samples/sec, Stonehenge-class 800x800 novel-view render",
+        "value": value,
+        "unit": "ray-samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"S-ring {H}x{Wd} novel-view render (synthetic Stonehenge stand-in, bound 2, dt_gamma 0, max_steps 1024), "
+                        f"hashgrid(16x2, 2^19, f16) + FFMLP(32-64-64-16 | 32-64-64-64-16) + occupancy march, path={args.path}",
+            "rays_per_frame": N,
+            "frames_per_gpu": args.steps,
+            "samples_per_ray": samples_per_launch / N,
+            "poses": n_poses,
+        },
+        "fps_per_gpu": 1e3 / ms_per_step,
+        "rays_capped_at_max_steps": capped,
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "k_render_frame" if args.path == "fused" else "per-op loop (many kernels)",
+            "avg_launch_ms": 1e3 * avg_kernel_s,
+            "algorithmic_bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
+            "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,
+        },
+    }
+
+    if not args.no_cpu and world == 1:
+        from oracle import ngp_oracle as O, render_oracle as R
+        O.build()
+        r = args.cpu_res
+        o, d = W.get_rays(W.orbit_pose(0, n_poses), W.intrinsics(r, r), r, r)
+        bitfield = ren.density_bitfield.cpu().numpy()
+        t1 = time.perf_counter()
+        ref = R.run_cuda(lambda x, dd: R.field_forward(model, x, dd, 1.0), o, d, bitfield, W.BOUND, 2)
+        cpu_s = time.perf_counter() - t1
+        gpu = ren.render_fused(torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None], bg_color=1)
+        img = gpu["image"][0].cpu().numpy()
+        result["psnr_vs_oracle_db"] = R.psnr(img, ref["image"])
+        result["max_abs_vs_oracle"] = float(np.max(np.abs(img - ref["image"])))
+        result["cpu_baseline"] = {
+            "value": ref["samples"] / cpu_s,
+            "unit": "ray-samples/s",
+            "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"one {r}x{r} frame of the same scene and model through oracle run_cuda "
+                      f"({ref['samples']} ray-samples, {cpu_s:.1f} s, OpenMP over all cores)",
+        }
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

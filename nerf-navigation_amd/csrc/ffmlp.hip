@@ -66,7 +66,7 @@ static void ffmlp_launch(bool save, const void* X, const void* W, uint32_t B, ui
 
 static int ffmlp_check(const char* who, const void* inputs, const void* weights, const void* outputs, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation) {
-    NGP_REQUIRE(inputs && weights && outputs, "%s: null pointer", who);
+    NGP_REQUIRE(B == 0 || (inputs && weights && outputs), "%s: null pointer", who);
     NGP_REQUIRE(hidden_dim == 64, "%s: hidden_dim must be 64 (the width every reference model uses)", who);
     NGP_REQUIRE(output_dim == 16, "%s: output_dim must be the padded width 16 (FFMLP pads, ffmlp.py:117)", who);
     NGP_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= 64, "%s: input_dim must be 16, 32, 48 or 64", who);
@@ -91,8 +91,8 @@ extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32
                                  void* forward_buffer, void* outputs, void* stream) {
     int rc = ffmlp_check("ffmlp_forward", inputs, weights, outputs, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NGP_OK) return rc;
-    NGP_REQUIRE(forward_buffer, "ffmlp_forward: null forward_buffer");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(forward_buffer, "ffmlp_forward: null forward_buffer");
     rc = ffmlp_dispatch(true, inputs, weights, B, input_dim, num_layers, forward_buffer, outputs, (hipStream_t)stream);
     if (rc != NGP_OK) return rc;
     NGP_CHECK_LAUNCH("ffmlp_forward");

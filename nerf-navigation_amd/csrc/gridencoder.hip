@@ -288,6 +288,7 @@ extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddin
                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                        int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners,
                                        int dtype, void* stream) {
+    if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
     NGP_REQUIRE(!calc_grad_inputs || dy_dx, "grid_encode_forward: calc_grad_inputs needs dy_dx");
     NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_forward: L must be in 1..32");
@@ -347,6 +348,7 @@ extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, c
                                         int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                         int align_corners, int dtype, void* stream) {
     (void)embeddings;                                  // kept for signature parity; the scatter never reads the table
+    if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     NGP_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs), "grid_encode_backward: calc_grad_inputs needs dy_dx and grad_inputs");
     NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_backward: L must be in 1..32");

@@ -116,6 +116,26 @@ struct ngp_pcg32 {
     }
 };
 
+// ray / AABB slab test (reference: raymarching.cu:109-146); miss => FLT_MAX for both
+__device__ __forceinline__ void ngp_near_far_inline(const float* o, const float* d, const float* aabb, float min_near,
+                                                    float& near, float& far) {
+    const float rdx = 1.0f / d[0], rdy = 1.0f / d[1], rdz = 1.0f / d[2];
+    float tn = (aabb[0] - o[0]) * rdx, tf = (aabb[3] - o[0]) * rdx;
+    if (tn > tf) { const float s = tn; tn = tf; tf = s; }
+    float yn = (aabb[1] - o[1]) * rdy, yf = (aabb[4] - o[1]) * rdy;
+    if (yn > yf) { const float s = yn; yn = yf; yf = s; }
+    if (tn > yf || yn > tf) { near = far = 3.402823466e+38f; return; }
+    if (yn > tn) tn = yn;
+    if (yf < tf) tf = yf;
+    float zn = (aabb[2] - o[2]) * rdz, zf = (aabb[5] - o[2]) * rdz;
+    if (zn > zf) { const float s = zn; zn = zf; zf = s; }
+    if (tn > zf || zn > tf) { near = far = 3.402823466e+38f; return; }
+    if (zn > tn) tn = zn;
+    if (zf < tf) tf = zf;
+    if (tn < min_near) tn = min_near;
+    near = tn; far = tf;
+}
+
 // ---------------------------------------------------------------------------
 // device: the occupancy march step shared by march_rays_train, march_rays and the fused renderer
 // (reference: raymarching.cu:363-404, 431-483, 759-813)

@@ -19,26 +19,6 @@ static constexpr uint32_t RM_BLOCK = 256;
 // near / far
 // ---------------------------------------------------------------------------
 
-__device__ __forceinline__ void ngp_near_far(const float* o, const float* d, const float* aabb, float min_near,
-                                             float& near, float& far) {
-    // reference: raymarching.cu:109-146
-    const float rdx = 1.0f / d[0], rdy = 1.0f / d[1], rdz = 1.0f / d[2];
-    float tn = (aabb[0] - o[0]) * rdx, tf = (aabb[3] - o[0]) * rdx;
-    if (tn > tf) { const float s = tn; tn = tf; tf = s; }
-    float yn = (aabb[1] - o[1]) * rdy, yf = (aabb[4] - o[1]) * rdy;
-    if (yn > yf) { const float s = yn; yn = yf; yf = s; }
-    if (tn > yf || yn > tf) { near = far = 3.402823466e+38f; return; }
-    if (yn > tn) tn = yn;
-    if (yf < tf) tf = yf;
-    float zn = (aabb[2] - o[2]) * rdz, zf = (aabb[5] - o[2]) * rdz;
-    if (zn > zf) { const float s = zn; zn = zf; zf = s; }
-    if (tn > zf || zn > tf) { near = far = 3.402823466e+38f; return; }
-    if (zn > tn) tn = zn;
-    if (zf < tf) tf = zf;
-    if (tn < min_near) tn = min_near;
-    near = tn; far = tf;
-}
-
 __global__ __launch_bounds__(RM_BLOCK) void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const float* __restrict__ aabb, uint32_t N, float min_near,
                                                        float* __restrict__ nears, float* __restrict__ fars) {
@@ -48,13 +28,14 @@ __global__ __launch_bounds__(RM_BLOCK) void k_near_far(const float* __restrict__
     #pragma unroll
     for (int i = 0; i < 6; i++) bb[i] = aabb[i];
     float near, far;
-    ngp_near_far(rays_o + 3ull * n, rays_d + 3ull * n, bb, min_near, near, far);
+    ngp_near_far_inline(rays_o + 3ull * n, rays_d + 3ull * n, bb, min_near, near, far);
     nears[n] = near;
     fars[n] = far;
 }
 
 extern "C" int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
                                       float min_near, float* nears, float* fars, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
     if (N == 0) return NGP_OK;
     hipLaunchKernelGGL(k_near_far, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
@@ -87,6 +68,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_sph_from_ray(const float* __restri
 }
 
 extern "C" int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
     if (N == 0) return NGP_OK;
     hipLaunchKernelGGL(k_sph_from_ray, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
@@ -134,6 +116,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_packbits(const float* __restrict__
 }
 
 extern "C" int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(coords && indices, "morton3D: null pointer");
     if (N == 0) return NGP_OK;
     hipLaunchKernelGGL(k_morton3D, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, coords, N, indices);
@@ -142,6 +125,7 @@ extern "C" int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices,
 }
 
 extern "C" int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(coords && indices, "morton3D_invert: null pointer");
     if (N == 0) return NGP_OK;
     hipLaunchKernelGGL(k_morton3D_invert, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, indices, N, coords);
@@ -150,6 +134,7 @@ extern "C" int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* 
 }
 
 extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(grid && bitfield, "packbits: null pointer");
     NGP_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15u) == 0, "packbits: grid must be 16-byte aligned");
     if (N == 0) return NGP_OK;
@@ -300,6 +285,7 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
                                     const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                                     int32_t* rays, int32_t* counter, uint32_t perturb,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter, "march_rays_train: null pointer");
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays_train: bad C/H/max_steps");
     NGP_REQUIRE(workspace && workspace_bytes >= ngp_march_rays_train_workspace(N), "march_rays_train: workspace too small");
@@ -389,6 +375,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_train_bwd(const float* _
 
 extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                                 uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null sample pointer");
     if (N == 0) return NGP_OK;
@@ -402,6 +389,7 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
                                                  const float* rgbs, const float* deltas, const int32_t* rays,
                                                  const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                                  float* grad_sigmas, float* grad_rgbs, void* stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, "composite_rays_train_backward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), "composite_rays_train_backward: null sample pointer");
     if (N == 0) return NGP_OK;
@@ -486,6 +474,7 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
                               const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                               uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                               float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
+    if (n_alive == 0 || n_step == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas, "march_rays: null pointer");
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
     if (n_alive == 0 || n_step == 0) return NGP_OK;
@@ -498,6 +487,7 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
 
 extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
                                   const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
+    if (n_alive == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "composite_rays: null pointer");
     if (n_alive == 0) return NGP_OK;
     hipLaunchKernelGGL(k_composite_rays, dim3(ngp_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,

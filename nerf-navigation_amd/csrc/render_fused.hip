@@ -1,13 +1,445 @@
-// render_fused.hip -- placeholder translation unit; replaced by the fused renderer.
-#include "ngp_device.h"
-extern "C" int ngp_field_forward(const ngp_field_t*, const float*, const float*, uint32_t, float*, float*, void*) {
-    return ngp_fail(NGP_EINVAL, "field_forward: not built");
+// render_fused.hip -- the fused inference path: field evaluation (hash grid -> density MLP -> SH -> colour MLP)
+// and a whole frame of NeRFRenderer.run_cuda's inference branch (nerf/renderer.py:325-374) in ONE launch.
+//
+// Why: the reference's loop is ~15 launches and one host sync per iteration, O(100) iterations per frame, with
+// every intermediate (xyzs, dirs, deltas, features, sigmas, rgbs: ~224 B per sample) making a round trip through
+// HBM.  Here a persistent grid of waves pulls rays from a queue; each lane owns one ray,
+// marches it to its next occupied sample, the wave evaluates the field for its 64 samples on the matrix cores,
+// each lane composites its own sample, and finished lanes are refilled from the queue.  Per-sample HBM/L2 traffic
+// is the hash-table gather only (512 B algorithmic); rays in and pixels out are amortised over the ray's samples.
+//
+// Work mapping inside a wave (wave64):
+//   march / composite : lane l <-> ray l                               (64 rays in flight per wave)
+//   field evaluation  : 4 passes; pass p evaluates the samples of lanes 16p..16p+15 as one 16-column MFMA tile.
+//                       In a pass, lane (g = l>>4, s = l&15) gathers levels 4g..4g+3 of column s's sample, which is
+//                       exactly its slice of the first layer's B fragment (features 8g..8g+7): the gather lands in
+//                       matrix-operand layout with no transpose.
+//   density MLP       : ngp_mlp.h (weights in VGPRs, activations never leave registers)
+//   colour MLP input  : the reference concatenates [SH(16), geo(15), 0] (nerf/network_ff.py:67-68).  A lane already
+//                       holds h[4g..4g+3] of the density output and computes SH[4g..4g+3] itself, so its B fragment
+//                       is {h[4g..4g+3], SH[4g..4g+3]} and the colour net's first-layer weights are loaded in that
+//                       same k order (column of h0 zeroed: it is the density logit, not a colour input).
+//
+// Semantics vs the reference loop (DESIGN.md "Fused path"): each ray is marched by a single resumable march from
+// `near` (the reference re-enters march_rays every n_step samples); a ray consumes at most max_steps samples (the
+// reference offers between max_steps and max_steps+7 depending on the schedule; such rays are counted in stats[1]).
+#include "ngp_mlp.h"
+#include "ngp_sh.h"
+
+static constexpr int RF_L = 16;       // levels (4 per lane group)
+static constexpr uint32_t RF_BLOCK = 256;
+
+struct rf_params {
+    const uint32_t* table;            // [sO] half2 rows
+    const int* offsets;               // [17]
+    const _Float16* w_sigma;          // 64*(32+64+16)
+    const _Float16* w_color;          // 64*(32+128+16)
+    float bound, density_scale;
+    float scale[RF_L];                // exp2f(l*S)*H - 1 (host)
+    uint32_t resolution[RF_L];        // ceil(scale)+1
+    sh_norm shn;
+};
+
+// per-lane constants of the 4 levels a lane group gathers
+struct rf_lane_levels {
+    float scale[4];
+    uint32_t base[4], size[4], s1[4], s2[4];   // row offset, rows, strides (dense) ; s1 == 0 marks a hashed level
+    uint32_t mask[4];                          // size-1 when size is a power of two, else 0
+};
+
+__device__ __forceinline__ void rf_setup_levels(const rf_params& P, int g, rf_lane_levels& lv) {
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // select by lane group from the scalar (kernarg) arrays
+        float sc = P.scale[i]; uint32_t rs = P.resolution[i];
+        if (g == 1) { sc = P.scale[4 + i]; rs = P.resolution[4 + i]; }
+        if (g == 2) { sc = P.scale[8 + i]; rs = P.resolution[8 + i]; }
+        if (g == 3) { sc = P.scale[12 + i]; rs = P.resolution[12 + i]; }
+        const int level = 4 * g + i;
+        const uint32_t o0 = (uint32_t)P.offsets[level], o1 = (uint32_t)P.offsets[level + 1];
+        const uint32_t size = o1 - o0;
+        // reference get_grid_index (gridencoder.cu:54-72): the stride stops growing once it exceeds hashmap_size
+        uint32_t stride = 1, s1 = 0, s2 = 0;
+        bool dense = true;
+        #pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (stride <= size) {
+                if (d == 1) s1 = stride;
+                if (d == 2) s2 = stride;
+                stride *= (rs + 1);
+            } else dense = false;
+        }
+        if (stride > size) dense = false;
+        lv.scale[i] = sc; lv.base[i] = o0; lv.size[i] = size;
+        lv.s1[i] = dense ? s1 : 0u; lv.s2[i] = dense ? s2 : 0u;
+        lv.mask[i] = ((size & (size - 1)) == 0) ? (size - 1) : 0u;
+    }
 }
-extern "C" size_t ngp_render_frame_workspace(uint32_t) { return 16; }
-extern "C" int ngp_render_frame(const ngp_field_t*, const float*, const float*, uint32_t, const float*, float, const uint8_t*, uint32_t,
-                                uint32_t, float, uint32_t, const float*, float*, float*, float*, uint32_t*, void*, size_t, void*) {
-    return ngp_fail(NGP_EINVAL, "render_frame: not built");
+
+__device__ __forceinline__ float rf_h(float v) { return (float)(_Float16)v; }   // round to half, back to float
+
+// Hash-grid encoding of one sample for the 4 levels of this lane's group -> 8 half features (k = 8g + 2i + ch).
+// Arithmetic identical, operation for operation, to k_grid_forward<_Float16,3,2> (gridencoder.hip).
+__device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, float wx, float wy, float wz) {
+    const float b2 = 2 * P.bound;
+    const float x0 = (wx + P.bound) / b2, x1 = (wy + P.bound) / b2, x2 = (wz + P.bound) / b2;   // GridEncoder.forward (grid.py:144)
+    const bool oob = (x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1);
+    uint32_t raw[4][8];
+    float fx[4], fy[4], fz[4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float sc = lv.scale[i];
+        float px = x0 * sc + 0.5f, py = x1 * sc + 0.5f, pz = x2 * sc + 0.5f;
+        const uint32_t gx = (uint32_t)floorf(px), gy = (uint32_t)floorf(py), gz = (uint32_t)floorf(pz);
+        fx[i] = px - (float)gx; fy[i] = py - (float)gy; fz[i] = pz - (float)gz;
+        uint32_t idx[8];
+        if (lv.s1[i] != 0u) {                          // dense level: x + y*s1 + z*s2 (always < size)
+            const uint32_t ay = gy * lv.s1[i], az = gz * lv.s2[i];
+            #pragma unroll
+            for (int c = 0; c < 8; c++)
+                idx[c] = (gx + (c & 1)) + (ay + ((c & 2) ? lv.s1[i] : 0u)) + (az + ((c & 4) ? lv.s2[i] : 0u));
+        } else {                                       // hashed level: x ^ y*p1 ^ z*p2 (fast_hash, gridencoder.cu:35-51)
+            const uint32_t hy = gy * 2654435761u, hz = gz * 805459861u;
+            #pragma unroll
+            for (int c = 0; c < 8; c++)
+                idx[c] = (gx + (c & 1)) ^ (hy + ((c & 2) ? 2654435761u : 0u)) ^ (hz + ((c & 4) ? 805459861u : 0u));
+            if (lv.mask[i] != 0u) {                    // 2^k rows (the usual 2^19): modulo is a mask
+                #pragma unroll
+                for (int c = 0; c < 8; c++) idx[c] &= lv.mask[i];
+            } else {
+                #pragma unroll
+                for (int c = 0; c < 8; c++) idx[c] %= lv.size[i];
+            }
+        }
+        const uint32_t* tab = P.table + lv.base[i];
+        #pragma unroll
+        for (int c = 0; c < 8; c++) raw[i][c] = oob ? 0u : tab[idx[c]];
+    }
+    ngp_h8 out;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float r0 = 0.0f, r1 = 0.0f;
+        #pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float w = (c & 1) ? fx[i] : 1 - fx[i];
+            w *= (c & 2) ? fy[i] : 1 - fy[i];
+            w *= (c & 4) ? fz[i] : 1 - fz[i];
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 v = __builtin_bit_cast(h2, raw[i][c]);
+            r0 = rf_h(r0 + rf_h(w * (float)v.x));
+            r1 = rf_h(r1 + rf_h(w * (float)v.y));
+        }
+        out[2 * i] = (_Float16)r0;
+        out[2 * i + 1] = (_Float16)r1;
+    }
+    if (oob) {
+        #pragma unroll
+        for (int j = 0; j < 8; j++) out[j] = (_Float16)0.0f;
+    }
+    return out;
 }
+
+// colour-net first layer, A fragments in the k order {h[4g..4g+3], SH[4g..4g+3]} (see the header comment)
+__device__ __forceinline__ ngp_h8 rf_load_a_color_in(const _Float16* __restrict__ W, int t, int lane) {
+    const int row = 16 * t + (lane & 15), g = lane >> 4;
+    ngp_h8 a;
+    #pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int hi = 4 * g + j;                      // index into the density net's output h
+        a[j] = (hi == 0) ? (_Float16)0.0f : W[row * 32 + 15 + hi];   // geo feature hi-1 sits at input column 16 + (hi-1)
+        a[4 + j] = W[row * 32 + 4 * g + j];            // SH feature 4g+j
+    }
+    return a;
+}
+
+struct rf_weights {
+    mlp_weights<1, 1> sig;                             // FFMLP(32 -> 64 -> 64 -> 16), num_layers 2
+    ngp_h8 c_in[MLP_MT];
+    ngp_h8 c_hid[2][MLP_MT][2];                        // FFMLP(32 -> 64 -> 64 -> 64 -> 16), num_layers 3
+    ngp_h8 c_out[2];
+    __device__ __forceinline__ void load(const rf_params& P, int lane) {
+        sig.load(P.w_sigma, 32, lane);
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) c_in[t] = rf_load_a_color_in(P.w_color, t, lane);
+        const _Float16* Wh = P.w_color + MLP_W * 32;
+        #pragma unroll
+        for (int h = 0; h < 2; h++)
+            #pragma unroll
+            for (int t = 0; t < MLP_MT; t++)
+                #pragma unroll
+                for (int c = 0; c < 2; c++) c_hid[h][t][c] = mlp_load_a_permuted(Wh + h * MLP_W * MLP_W, MLP_W, t, c, lane);
+        #pragma unroll
+        for (int c = 0; c < 2; c++) c_out[c] = mlp_load_a_permuted(Wh + 2 * MLP_W * MLP_W, MLP_W, 0, c, lane);
+    }
+};
+
+// One 16-column tile: (world position, direction) of column s's sample, held redundantly by its 4 lanes.
+// Returns, valid in lanes g == 0: sigma (already times density_scale) and rgb.
+__device__ __forceinline__ void rf_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_weights& W, int g,
+                                              float px, float py, float pz, float dx, float dy, float dz,
+                                              float& sigma, float& cr, float& cg, float& cb) {
+    ngp_h8 x[1];
+    x[0] = rf_encode(P, lv, px, py, pz);
+    const ngp_f4 h = mlp_forward_tile<1, 1>(W.sig, x, [](int, const ngp_h8 (&)[2]) {});
+
+    float sh[16];
+    sh_eval<4>(dx, dy, dz, P.shn, sh);
+    ngp_h8 cin;
+    #pragma unroll
+    for (int j = 0; j < 4; j++) {
+        cin[j] = (_Float16)h[j];                       // density-net output, rounded to half (FFMLP output dtype)
+        float s = sh[j];
+        if (g == 1) s = sh[4 + j];
+        if (g == 2) s = sh[8 + j];
+        if (g == 3) s = sh[12 + j];
+        cin[4 + j] = (_Float16)s;                      // cat(...) enters FFMLP through cast_inputs=half
+    }
+    ngp_h8 act[2];
+    {
+        ngp_f4 d[MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(W.c_in[t], cin, ngp_f4{0.f, 0.f, 0.f, 0.f});
+        act[0] = mlp_pack_relu(d[0], d[1]);
+        act[1] = mlp_pack_relu(d[2], d[3]);
+    }
+    #pragma unroll
+    for (int l = 0; l < 2; l++) {
+        ngp_f4 d[MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) {
+            d[t] = ngp_mfma(W.c_hid[l][t][0], act[0], ngp_f4{0.f, 0.f, 0.f, 0.f});
+            d[t] = ngp_mfma(W.c_hid[l][t][1], act[1], d[t]);
+        }
+        act[0] = mlp_pack_relu(d[0], d[1]);
+        act[1] = mlp_pack_relu(d[2], d[3]);
+    }
+    ngp_f4 o = ngp_mfma(W.c_out[0], act[0], ngp_f4{0.f, 0.f, 0.f, 0.f});
+    o = ngp_mfma(W.c_out[1], act[1], o);
+
+    // lanes g == 0 hold h0 (row 0 of the density tile) and rows 0..2 of the colour tile
+    sigma = P.density_scale * ngp_expf(rf_h(h[0]));                                   // trunc_exp forward (activation.py:9-10), fp32
+    cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[0]))));                                 // torch.sigmoid on a half tensor
+    cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[1]))));
+    cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[2]))));
+}
+
+// ---------------------------------------------------------------------------
+// field_forward: sigma / rgb for explicit points
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RF_BLOCK) void k_field_forward(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
+                                                            uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+    const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
+    rf_lane_levels lv;
+    rf_setup_levels(P, g, lv);
+    rf_weights W;
+    W.load(P, lane);
+    const uint32_t ntiles = (M + 15) >> 4;
+    for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
+        const uint32_t m = tile * 16 + s;
+        const bool valid = m < M;
+        const uint64_t mm = valid ? m : 0;
+        const float px = xyzs[3 * mm], py = xyzs[3 * mm + 1], pz = xyzs[3 * mm + 2];
+        const float dx = dirs[3 * mm], dy = dirs[3 * mm + 1], dz = dirs[3 * mm + 2];
+        float sigma, cr, cg, cb;
+        rf_field_tile(P, lv, W, g, px, py, pz, dx, dy, dz, sigma, cr, cg, cb);
+        if (g == 0 && valid) {
+            sigmas[m] = sigma;
+            rgbs[3ull * m] = cr; rgbs[3ull * m + 1] = cg; rgbs[3ull * m + 2] = cb;
+        }
+    }
+}
+
+static int rf_fill_params(const char* who, const ngp_field_t* f, rf_params& P) {
+    NGP_REQUIRE(f && f->embeddings && f->offsets && f->sigma_weights && f->color_weights, "%s: null field pointer", who);
+    NGP_REQUIRE(f->L == RF_L, "%s: the fused path is built for 16 levels x 2 features (the reference's hashgrid)", who);
+    NGP_REQUIRE(f->bound > 0, "%s: bound must be positive", who);
+    P.table = (const uint32_t*)f->embeddings;
+    P.offsets = f->offsets;
+    P.w_sigma = (const _Float16*)f->sigma_weights;
+    P.w_color = (const _Float16*)f->color_weights;
+    P.bound = f->bound;
+    P.density_scale = f->density_scale;
+    for (int l = 0; l < RF_L; l++) {
+        P.scale[l] = exp2f((float)l * f->S) * (float)f->H - 1.0f;
+        P.resolution[l] = (uint32_t)ceilf(P.scale[l]) + 1u;
+    }
+    sh_fill_norm(P.shn);
+    return NGP_OK;
+}
+
+extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
+                                 float* sigmas, float* rgbs, void* stream) {
+    rf_params P;
+    int rc = rf_fill_params("field_forward", field_host, P);
+    if (rc != NGP_OK) return rc;
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && dirs && sigmas && rgbs, "field_forward: null pointer");
+    const uint32_t ntiles = (M + 15) >> 4;
+    uint32_t blocks = ngp_div_up(ntiles, 4 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_field_forward, dim3(blocks), dim3(RF_BLOCK), 0, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs);
+    NGP_CHECK_LAUNCH("field_forward");
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// render_frame: persistent waves, one ray per lane, ray queue in global memory
+// ---------------------------------------------------------------------------
+
+struct rf_frame {
+    const float* rays_o; const float* rays_d; uint32_t N;
+    float aabb[6]; float min_near;
+    const uint8_t* bitfield; uint32_t C, H;
+    float dt_gamma; uint32_t max_steps;
+    float bg[3];
+    float* image; float* depth; float* weights_sum;
+    uint32_t* stats; uint32_t* queue;
+};
+
+__global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame F) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+    rf_lane_levels lv;
+    rf_setup_levels(P, g, lv);
+    rf_weights W;
+    W.load(P, lane);
+
+    // per-lane ray state
+    bool active = false;
+    uint32_t ray = 0, nsamp = 0;
+    ngp_march_t m;
+    float t = 0, last_t = 0, near = 0, far = 0;
+    float ws = 0, dacc = 0, cr = 0, cg = 0, cb = 0, tcomp = 0;
+    bool exhausted = false;
+    uint32_t n_samples_local = 0;
+
+    for (;;) {
+        // ---- refill finished lanes from the queue (one atomic per wave) ----
+        if (!exhausted) {
+            const unsigned long long need = __ballot(!active);
+            if (need) {
+                const uint32_t cnt = (uint32_t)__popcll(need);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(F.queue, cnt);
+                base = __shfl(base, 0, 64);
+                if (!active) {
+                    const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                    if (idx < F.N) {
+                        ray = idx;
+                        const float* o = F.rays_o + 3ull * idx;
+                        const float* d = F.rays_d + 3ull * idx;
+                        ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
+                        m.setup(o, d, P.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.bitfield);
+                        t = near; last_t = near; tcomp = near;
+                        ws = 0; dacc = 0; cr = 0; cg = 0; cb = 0; nsamp = 0;
+                        active = true;
+                    }
+                }
+                if (base + cnt >= F.N) exhausted = true;
+            }
+        }
+        if (__ballot(active) == 0ull) break;            // queue drained and every ray of this wave is finished
+
+        // ---- march each active lane to its next occupied sample ----
+        bool has = false;
+        float x = 0, y = 0, z = 0, dt = 0, d1 = 0;
+        if (active) {
+            while (t < far && nsamp < F.max_steps) {
+                if (m.probe(t, x, y, z, dt)) { has = true; break; }
+            }
+            if (has) {
+                t += dt;
+                d1 = t - last_t;
+                last_t = t;
+                nsamp++;
+            }
+        }
+
+        // ---- field evaluation: 4 passes of 16 columns ----
+        float sig = 0, sr = 0, sg = 0, sb = 0;
+        #pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int src = 16 * p + s;
+            const bool v = __shfl((int)has, src, 64) != 0;
+            if (__ballot(v) == 0ull) continue;           // wave-uniform: nothing to evaluate in this pass
+            const float qx = __shfl(x, src, 64), qy = __shfl(y, src, 64), qz = __shfl(z, src, 64);
+            const float ex = __shfl(m.dx, src, 64), ey = __shfl(m.dy, src, 64), ez = __shfl(m.dz, src, 64);
+            float a, b, c, d;
+            rf_field_tile(P, lv, W, g, qx, qy, qz, ex, ey, ez, a, b, c, d);
+            // results live in lanes 0..15 (g == 0); hand column s's result to lane 16p + s
+            const float ra = __shfl(a, s, 64), rb = __shfl(b, s, 64), rc = __shfl(c, s, 64), rd = __shfl(d, s, 64);
+            if (g == p) { sig = ra; sr = rb; sg = rc; sb = rd; }
+        }
+
+        // ---- composite (kernel_composite_rays arithmetic, raymarching.cu:865-896) ----
+        bool done = active && !has;                      // no further sample: t >= far or the sample cap
+        if (has) {
+            n_samples_local++;
+            const float alpha = 1.0f - ngp_expf(-sig * dt);
+            const float T = 1 - ws;
+            const float w = alpha * T;
+            ws += w;
+            tcomp += d1;
+            dacc += w * tcomp;
+            cr += w * sr; cg += w * sg; cb += w * sb;
+            if ((double)T < 1e-4) done = true;
+        }
+        if (done) {
+            // nerf/renderer.py:371-372
+            F.image[3ull * ray] = cr + (1 - ws) * F.bg[0];
+            F.image[3ull * ray + 1] = cg + (1 - ws) * F.bg[1];
+            F.image[3ull * ray + 2] = cb + (1 - ws) * F.bg[2];
+            F.depth[ray] = fmaxf(dacc - near, 0.0f) / (far - near);
+            F.weights_sum[ray] = ws;
+            if (nsamp >= F.max_steps && t < far) atomicAdd(F.stats + 1, 1u);
+            if (nsamp > 0) atomicAdd(F.stats + 2, 1u);
+            active = false;
+        }
+    }
+    // one atomic per wave for the sample count
+    uint32_t tot = n_samples_local;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    if (lane == 0 && tot) atomicAdd(F.stats, tot);
+}
+
+extern "C" size_t ngp_render_frame_workspace(uint32_t N) { (void)N; return 64; }
+
+extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
+                                const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                                float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                                float* image, float* depth, float* weights_sum, uint32_t* stats,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    rf_params P;
+    int rc = rf_fill_params("render_frame", field_host, P);
+    if (rc != NGP_OK) return rc;
+    NGP_REQUIRE(stats && workspace && workspace_bytes >= 64, "render_frame: stats / workspace missing");
+    NGP_REQUIRE(aabb_host && bg_color3_host, "render_frame: aabb / bg_color are host pointers and must not be null");
+    NGP_REQUIRE(C >= 1 && C <= 16 && Hgrid >= 1 && Hgrid <= 1024 && max_steps >= 1, "render_frame: bad C/H/max_steps");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(workspace, 0, 64, s) != hipSuccess)
+        return ngp_fail(NGP_ELAUNCH, "render_frame: memset failed");
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && bitfield && image && depth && weights_sum, "render_frame: null pointer");
+    rf_frame F;
+    F.rays_o = rays_o; F.rays_d = rays_d; F.N = N;
+    for (int i = 0; i < 6; i++) F.aabb[i] = aabb_host[i];
+    F.min_near = min_near; F.bitfield = bitfield; F.C = C; F.H = Hgrid;
+    F.dt_gamma = dt_gamma; F.max_steps = max_steps;
+    for (int i = 0; i < 3; i++) F.bg[i] = bg_color3_host[i];
+    F.image = image; F.depth = depth; F.weights_sum = weights_sum;
+    F.stats = stats; F.queue = (uint32_t*)workspace;
+    // persistent grid: 2 workgroups (8 waves, 512 rays in flight) per CU, fewer when the frame is small
+    uint32_t blocks = 256 * 2;
+    const uint32_t need = ngp_div_up(N, RF_BLOCK);
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(k_render_frame, dim3(blocks), dim3(RF_BLOCK), 0, s, P, F);
+    NGP_CHECK_LAUNCH("render_frame");
+    return NGP_OK;
+}
+
+// placeholder until the training path lands (ffmlp backward)
 extern "C" size_t ngp_ffmlp_backward_workspace(uint32_t, uint32_t, uint32_t, uint32_t) { return 16; }
 extern "C" int ngp_ffmlp_backward(const void*, const void*, const void*, const void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
                                   uint32_t, uint32_t, int, void*, void*, void*, void*, size_t, void*) {

@@ -15,22 +15,7 @@
 // These are the reference's polynomials exactly (it also treats x, y, z as independent and uses the unit-sphere
 // form in z), evaluated in a different order, so results agree to binary32 rounding (tests: 2e-6 abs at degree 4).
 // Bound: 12 B in, 4*C^2 (+ 12*C^2) B out per sample -- pure HBM streaming, negligible next to the grid encoder.
-#include "ngp_device.h"
-#include <math.h>
-
-static constexpr uint32_t SH_MAX = 8;
-
-struct sh_norm { float n[SH_MAX][SH_MAX]; };      // n[l][m], m <= l
-
-static void sh_fill_norm(sh_norm& t) {
-    for (uint32_t l = 0; l < SH_MAX; l++)
-        for (uint32_t m = 0; m <= l; m++) {
-            double r = 1.0;                        // (l-m)! / (l+m)!
-            for (uint32_t k = l - m + 1; k <= l + m; k++) r /= (double)k;
-            const double v = sqrt((m == 0 ? 1.0 : 2.0) * (2.0 * l + 1.0) / (4.0 * M_PI) * r);
-            t.n[l][m] = (float)((m & 1u) ? -v : v);
-        }
-}
+#include "ngp_sh.h"
 
 template <uint32_t C, bool GRAD>
 __global__ __launch_bounds__(256) void k_sh_forward(const float* __restrict__ inputs, float* __restrict__ outputs,
@@ -38,32 +23,11 @@ __global__ __launch_bounds__(256) void k_sh_forward(const float* __restrict__ in
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const float x = inputs[(uint64_t)b * D], y = inputs[(uint64_t)b * D + 1], z = inputs[(uint64_t)b * D + 2];
-
-    float A[C], Bm[C];
-    A[0] = 1.0f; Bm[0] = 0.0f;
-    #pragma unroll
-    for (uint32_t m = 1; m < C; m++) {
-        A[m] = x * A[m - 1] - y * Bm[m - 1];
-        Bm[m] = x * Bm[m - 1] + y * A[m - 1];
-    }
-
-    // Q[l][m] for m <= l; Q[l][l+1] = 0 closes the z-derivative
-    float Q[C][C + 1];
-    #pragma unroll
-    for (uint32_t m = 0; m < C; m++) {
-        float dfact = 1.0f;                         // (2m-1)!!
-        #pragma unroll
-        for (uint32_t k = 1; k <= m; k++) dfact *= (float)(2 * k - 1);
-        Q[m][m] = dfact;
-        Q[m][m + 1] = 0.0f;
-        if (m + 1 < C) Q[m + 1][m] = (float)(2 * m + 1) * z * dfact;
-        #pragma unroll
-        for (uint32_t l = m + 2; l < C; l++) {
-            const float a = (float)(2 * l - 1) / (float)(l - m);
-            const float c = (float)(l + m - 1) / (float)(l - m);
-            Q[l][m] = a * z * Q[l - 1][m] - c * Q[l - 2][m];
-        }
-    }
+    sh_tables<C> tb;
+    tb.build(x, y, z);
+    const float (&A)[C] = tb.A;
+    const float (&Bm)[C] = tb.B;
+    const float (&Q)[C][C + 1] = tb.Q;
 
     float* out = outputs + (uint64_t)b * C * C;
     float* jx = dy_dx + (uint64_t)b * D * C * C;
@@ -118,11 +82,11 @@ static void sh_launch(const float* inputs, float* outputs, uint32_t B, uint32_t 
 
 extern "C" int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C,
                                      int calc_grad_inputs, float* dy_dx, void* stream) {
+    if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && outputs, "sh_encode_forward: null pointer");
     NGP_REQUIRE(D == 3, "SH encoder only support input dim == 3");
     NGP_REQUIRE(C >= 1 && C <= SH_MAX, "SH encoder only supports degree in [1, 8]");
     NGP_REQUIRE(!calc_grad_inputs || dy_dx, "sh_encode_forward: calc_grad_inputs needs dy_dx");
-    if (B == 0) return NGP_OK;
     sh_norm nrm;
     sh_fill_norm(nrm);
     hipStream_t s = (hipStream_t)stream;
@@ -144,9 +108,9 @@ extern "C" int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32
 extern "C" int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                                       const float* dy_dx, float* grad_inputs, void* stream) {
     (void)inputs;
+    if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && dy_dx && grad_inputs, "sh_encode_backward: null pointer");
     NGP_REQUIRE(D == 3 && C >= 1 && C <= SH_MAX, "sh_encode_backward: D must be 3 and degree in [1, 8]");
-    if (B == 0) return NGP_OK;
     hipLaunchKernelGGL(k_sh_backward, dim3(ngp_div_up((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream,
                        grad, B, D, C * C, dy_dx, grad_inputs);
     NGP_CHECK_LAUNCH("sh_encode_backward");

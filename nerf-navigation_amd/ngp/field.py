@@ -1,0 +1,195 @@
+"""The reference's field models on top of the drop-in ops.
+
+`NGPFieldFF` mirrors nerf/network_ff.py:11-148 (hash grid -> FFMLP -> trunc_exp ; SH ++ geo ++ 0 -> FFMLP -> sigmoid),
+`NGPField` mirrors nerf/network.py:10-206 (the same field with bias-free nn.Linear layers).  Both keep the reference's
+method names (forward / density / color / get_params) and tensor contracts so that a torch-ngp style renderer or the
+nav/ lambdas (simulate.py:343-347) can call them unchanged.  `fused_state()` packs the FF model for the one-launch
+kernels of csrc/render_fused.hip.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+import ngp_hip as _hip
+from ffmlp import FFMLP
+from gridencoder import GridEncoder
+from shencoder import SHEncoder
+
+
+class _trunc_exp(Function):
+    """activation.py:5-18 : exp forward in float32, gradient through exp(clamp(x, -15, 15))."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x = ctx.saved_tensors[0]
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _trunc_exp.apply
+
+
+def get_encoder(encoding, input_dim=3, degree=4, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                desired_resolution=2048, align_corners=False, **kwargs):
+    """encoding.py:45-77 for the encoders on the hot path."""
+    if encoding == "None":
+        return (lambda x, **kw: x), input_dim
+    if encoding == "sphere_harmonics":
+        enc = SHEncoder(input_dim=input_dim, degree=degree)
+    elif encoding in ("hashgrid", "tiledgrid"):
+        enc = GridEncoder(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim, base_resolution=base_resolution,
+                          log2_hashmap_size=log2_hashmap_size, desired_resolution=desired_resolution,
+                          gridtype="hash" if encoding == "hashgrid" else "tiled", align_corners=align_corners)
+    else:
+        raise NotImplementedError("Unknown encoding mode, choose from [None, sphere_harmonics, hashgrid, tiledgrid]")
+    return enc, enc.output_dim
+
+
+class NGPFieldFF(nn.Module):
+    """nerf/network_ff.py: density net FFMLP(32,16,64,num_layers=2), colour net FFMLP(32,3,64,num_layers=3)."""
+
+    def __init__(self, bound=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
+                 density_scale=1):
+        super().__init__()
+        self.bound = bound
+        self.density_scale = density_scale
+        self.geo_feat_dim = geo_feat_dim
+        self.encoder, self.in_dim = get_encoder("hashgrid", desired_resolution=2048 * bound)
+        self.sigma_net = FFMLP(input_dim=self.in_dim, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
+        self.encoder_dir, self.in_dim_color = get_encoder("sphere_harmonics")
+        self.in_dim_color += geo_feat_dim + 1                      # padded to 32 (network_ff.py:42)
+        self.color_net = FFMLP(input_dim=self.in_dim_color, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
+        self._fused = None
+
+    def forward(self, x, d):
+        x = self.encoder(x, bound=self.bound)
+        h = self.sigma_net(x)
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:]
+        d = self.encoder_dir(d)
+        p = torch.zeros_like(geo_feat[..., :1])
+        h = self.color_net(torch.cat([d, geo_feat, p], dim=-1))
+        return sigma, torch.sigmoid(h)
+
+    def density(self, x):
+        x = self.encoder(x, bound=self.bound)
+        h = self.sigma_net(x)
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+        d = self.encoder_dir(d)
+        p = torch.zeros_like(geo_feat[..., :1])
+        h = torch.sigmoid(self.color_net(torch.cat([d, geo_feat, p], dim=-1)))
+        if mask is not None:
+            rgbs[mask] = h.to(rgbs.dtype)
+            return rgbs
+        return h
+
+    def get_params(self, lr):
+        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]
+
+    # ---- fused path -------------------------------------------------------------------------------------------
+    def load_arrays(self, model):
+        """Load a workload.make_model() dict (float32 arrays in the module's own layouts)."""
+        with torch.no_grad():
+            self.encoder.embeddings.copy_(torch.from_numpy(model["embeddings"]))
+            self.sigma_net.weights.copy_(torch.from_numpy(model["sigma_weights"]))
+            self.color_net.weights.copy_(torch.from_numpy(model["color_weights"]))
+        self._fused = None
+        return self
+
+    def fused_state(self):
+        """Half copies of table and weights plus the ngp_field_t describing them (include/ngp_hip.h).  The reference
+        converts the table to half on EVERY forward under autocast (gridencoder/grid.py:38-39: a 50 MB read + 25 MB
+        write per call); the fused path keeps the half table resident and rebuilds it only when parameters change."""
+        key = (self.encoder.embeddings._version, self.sigma_net.weights._version, self.color_net.weights._version)
+        if self._fused is None or self._fused["key"] != key:
+            emb = self.encoder.embeddings.detach().to(torch.half).contiguous()
+            ws = self.sigma_net.weights.detach().to(torch.half).contiguous()
+            wc = self.color_net.weights.detach().to(torch.half).contiguous()
+            f = _hip.ngp_field_t(emb.data_ptr(), self.encoder.offsets.data_ptr(), ws.data_ptr(), wc.data_ptr(),
+                                 self.encoder.num_levels, self.encoder.base_resolution,
+                                 float(np.log2(self.encoder.per_level_scale)), float(self.bound), float(self.density_scale))
+            self._fused = {"key": key, "tensors": (emb, ws, wc), "struct": f}
+        return self._fused["struct"]
+
+    @torch.no_grad()
+    def forward_fused(self, x, d):
+        """sigma (already times density_scale) and rgb for [M,3] points / directions in one launch (float32 out)."""
+        x, d = x.contiguous().float(), d.contiguous().float()
+        M = x.shape[0]
+        sig = torch.empty(M, dtype=torch.float32, device=x.device)
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        f = self.fused_state()
+        _hip.check(_hip.lib().ngp_field_forward(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb),
+                                                _hip.stream()), "field_forward")
+        return sig, rgb
+
+
+class NGPField(nn.Module):
+    """nerf/network.py: the same field with nn.Linear(bias=False) layers (32->64->16 ; 31->64->64->3)."""
+
+    def __init__(self, bound=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
+                 density_scale=1):
+        super().__init__()
+        self.bound = bound
+        self.density_scale = density_scale
+        self.num_layers, self.num_layers_color, self.geo_feat_dim = num_layers, num_layers_color, geo_feat_dim
+        self.encoder, self.in_dim = get_encoder("hashgrid", desired_resolution=2048 * bound)
+        dims = [self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]
+        self.sigma_net = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers)])
+        self.encoder_dir, self.in_dim_dir = get_encoder("sphere_harmonics")
+        dims = [self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3]
+        self.color_net = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers_color)])
+
+    @staticmethod
+    def _mlp(layers, h):
+        for i, layer in enumerate(layers):
+            h = layer(h)
+            if i != len(layers) - 1:
+                h = F.relu(h, inplace=True)
+        return h
+
+    def forward(self, x, d):
+        h = self._mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:]
+        h = self._mlp(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1))
+        return sigma, torch.sigmoid(h)
+
+    def density(self, x):
+        h = self._mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+        h = torch.sigmoid(self._mlp(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1)))
+        if mask is not None:
+            rgbs[mask] = h.to(rgbs.dtype)
+            return rgbs
+        return h
+
+    def get_params(self, lr):
+        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]

@@ -98,11 +98,21 @@ def check(rc, what=""):
         raise RuntimeError(f"libngp_hip {what} failed ({rc}): {msg}")
 
 
+class _DevPtr:
+    """A device pointer that keeps its tensor alive: ctypes reads `_as_parameter_`, and the argument tuple holds this
+    object until the call returns, so `ptr(x.contiguous())` can never hand the kernel freed memory."""
+    __slots__ = ("tensor", "_as_parameter_")
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self._as_parameter_ = ctypes.c_void_p(tensor.data_ptr())
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return _DevPtr(t)
 
 
 def stream():

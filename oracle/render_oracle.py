@@ -1,0 +1,132 @@
+"""CPU restatement of the render pipeline around the native ops (numpy + oracle/ngp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product package.
+
+  field_forward      NeRFNetwork.forward of nerf/network_ff.py:51-77 under autocast(fp16): where each tensor is rounded
+                     to half and where it is float32 follows the reference's custom_fwd casts
+                     (grid.py:38-39, ffmlp.py:18, activation.py:7, sphere_harmonics.py:16).
+  run_cuda           NeRFRenderer.run_cuda, inference branch (nerf/renderer.py:325-374): the n_step schedule, the
+                     128-row padding, the stable compaction, the background mix and the depth normalisation.
+  render_single_march  the semantics of the fused kernel: one resumable march per ray, at most max_steps samples.
+  psnr               PSNRMeter.update (nerf/utils.py:203-210).
+Parity unpinned by reference fixtures (it has none); pinned by the relations in tests/test_oracle_*.py.
+"""
+import numpy as np
+
+from . import ngp_oracle as O
+from . import sh_oracle
+
+
+def field_forward(model, xyzs, dirs, density_scale=1.0):
+    """model: dict from workload.make_model (float32 params).  Returns sigma [M] f32 (times density_scale), rgb [M,3] f32."""
+    bound = np.float32(model["bound"])
+    x = np.ascontiguousarray(xyzs, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    M = x.shape[0]
+    x01 = ((x + bound) / (np.float32(2) * bound)).astype(np.float32)                    # gridencoder/grid.py:144
+    emb = model["embeddings"].astype(np.float16)                                        # grid.py:38-39 (autocast)
+    feats, _ = O.grid_encode_forward(x01, emb, model["offsets"], model["per_level_scale"], 16, False, 0, False)
+    feats = np.ascontiguousarray(feats.transpose(1, 0, 2).reshape(M, 32))               # grid.py:52
+    pad = (-M) % 16
+    if pad:
+        feats = np.concatenate([feats, np.zeros((pad, 32), np.float16)])
+    h, _ = O.ffmlp_forward(feats, model["sigma_weights"].astype(np.float16), 32, 16, 64, 2)
+    h = h[:M]
+    sigma = O.expf(h[:, 0].astype(np.float32)) * np.float32(density_scale)              # trunc_exp, float32
+    sh = sh_oracle.sh_encode(d, 4).astype(np.float32)                                   # SHEncoder output is float32
+    cin = np.concatenate([sh.astype(np.float16), h[:, 1:], np.zeros((M, 1), np.float16)], axis=1)   # network_ff.py:67-68
+    if pad:
+        cin = np.concatenate([cin, np.zeros((pad, 32), np.float16)])
+    c, _ = O.ffmlp_forward(np.ascontiguousarray(cin), model["color_weights"].astype(np.float16), 32, 16, 64, 3)
+    c = c[:M, :3].astype(np.float32)
+    rgb = (np.float32(1) / (np.float32(1) + O.expf(-c))).astype(np.float16).astype(np.float32)   # sigmoid on a half tensor
+    return sigma.astype(np.float32), rgb
+
+
+def _finish(image, depth, weights_sum, nears, fars, bg_color):
+    image = image + (1 - weights_sum)[:, None] * np.float32(bg_color)                   # nerf/renderer.py:371
+    with np.errstate(invalid="ignore", divide="ignore"):
+        depth = np.clip(depth - nears, 0, None) / (fars - nears)                        # :372 (0/0 = NaN for missing rays)
+    return image.astype(np.float32), depth.astype(np.float32)
+
+
+def run_cuda(field_fn, rays_o, rays_d, bitfield, bound, cascade, H=128, min_near=0.2, dt_gamma=0.0, max_steps=1024,
+             bg_color=1.0, perturb=False, trace=None):
+    """field_fn(xyzs, dirs) -> (sigma already times density_scale, rgb).  Returns dict(image, depth, weights_sum, samples)."""
+    rays_o = np.ascontiguousarray(rays_o, np.float32).reshape(-1, 3)
+    rays_d = np.ascontiguousarray(rays_d, np.float32).reshape(-1, 3)
+    N = rays_o.shape[0]
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = O.near_far_from_aabb(rays_o, rays_d, aabb, min_near)
+    ws, depth, image = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    step, samples = 0, 0
+    while step < max_steps:
+        n_alive = alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = O.march_rays(n_alive, n_step, alive, rays_t, rays_o, rays_d, bound, bitfield, cascade, H,
+                                          nears, fars, 128, perturb, dt_gamma, max_steps)
+        sig, rgb = field_fn(xyzs, dirs)                                                 # padded rows are evaluated too
+        O.composite_rays(n_alive, n_step, alive, rays_t, sig, rgb, deltas, ws, depth, image)
+        k = int((deltas[:, 0] > 0).sum())
+        samples += k
+        if trace is not None:
+            trace.append((n_alive, n_step, k))
+        alive = np.ascontiguousarray(alive[alive >= 0])
+        step += n_step
+    image, depth = _finish(image, depth, ws, nears, fars, bg_color)
+    return dict(image=image, depth=depth, weights_sum=ws, samples=samples)
+
+
+def render_single_march(field_fn, rays_o, rays_d, bitfield, bound, cascade, H=128, min_near=0.2, dt_gamma=0.0,
+                        max_steps=1024, bg_color=1.0, chunk=2048):
+    """One march per ray from `near`, at most max_steps samples, composited with kernel_composite_rays' arithmetic."""
+    rays_o = np.ascontiguousarray(rays_o, np.float32).reshape(-1, 3)
+    rays_d = np.ascontiguousarray(rays_d, np.float32).reshape(-1, 3)
+    N = rays_o.shape[0]
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = O.near_far_from_aabb(rays_o, rays_d, aabb, min_near)
+    ws, depth, image = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    marched = np.zeros(N, np.int64)
+    consumed = np.zeros(N, np.int64)
+    for head in range(0, N, chunk):
+        idx = np.arange(head, min(head + chunk, N), dtype=np.int32)
+        n = idx.shape[0]
+        rays_t = nears.copy()
+        xyzs, dirs, deltas = O.march_rays(n, max_steps, idx, rays_t, rays_o, rays_d, bound, bitfield, cascade, H, nears, fars,
+                                          -1, False, dt_gamma, max_steps)
+        live = deltas[:, 0] > 0
+        sig = np.zeros(xyzs.shape[0], np.float32)
+        rgb = np.zeros((xyzs.shape[0], 3), np.float32)
+        if live.any():
+            s, c = field_fn(xyzs[live], dirs[live])
+            sig[live], rgb[live] = s, c
+        # samples consumed by the compositor: up to and including the one whose incoming T is below 1e-4
+        # (same float32 recurrence as kernel_composite_rays, vectorised over the rays of the chunk)
+        d0 = deltas[:, 0].reshape(n, max_steps)
+        sg = sig.reshape(n, max_steps)
+        run_ws = np.zeros(n, np.float32)
+        going = np.ones(n, bool)
+        used = np.zeros(n, np.int64)
+        for k in range(max_steps):
+            has = going & (d0[:, k] > 0)
+            if not has.any():
+                break
+            alpha = np.float32(1) - O.expf(-sg[:, k] * d0[:, k])
+            T = np.float32(1) - run_ws
+            run_ws = np.where(has, run_ws + alpha * T, run_ws).astype(np.float32)
+            used += has
+            going = has & ~(T.astype(np.float64) < 1e-4)
+        consumed[idx] = used
+        marched[idx] = (d0 > 0).sum(1)
+        alive = idx.copy()
+        O.composite_rays(n, max_steps, alive, rays_t, sig, rgb, deltas, ws, depth, image)
+    image, depth = _finish(image, depth, ws, nears, fars, bg_color)
+    return dict(image=image, depth=depth, weights_sum=ws, marched=marched, consumed=consumed, samples=int(consumed.sum()))
+
+
+def psnr(pred, truth):
+    return float(-10 * np.log10(np.mean((np.asarray(pred, np.float64) - np.asarray(truth, np.float64)) ** 2)))

@@ -33,7 +33,7 @@ def test_ffmlp_exact_integer_data(oracle, dev, input_dim, num_layers):
     B = 16 * 37
     nw = oracle.ffmlp_num_params(input_dim, 16, 64, num_layers)
     # weights in {-1, 0, 1} (sparse), inputs small non-negative integers: all activations stay small integers, exact in half
-    w = rng.choice([-1.0, 0.0, 0.0, 0.0, 1.0], size=nw).astype(np.float16)
+    w = rng.choice([-1.0, 0, 0, 0, 0, 0, 0, 1.0], size=nw).astype(np.float16)
     x = rng.integers(0, 3, size=(B, input_dim)).astype(np.float16)
     ref, fb_ref = oracle.ffmlp_forward(x, w, input_dim, 16, 64, num_layers, save=True)
     assert np.abs(ref.astype(np.float32)).max() < 2048 and np.abs(ref.astype(np.float32)).max() > 3
