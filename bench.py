@@ -75,7 +75,7 @@ def main():
     def frame(k):
         o, d = rays[k % n_poses]
         if args.path == "fused":
-            return ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024)
+            return ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024)
 

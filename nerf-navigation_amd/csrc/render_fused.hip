@@ -28,6 +28,9 @@
 
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
+#ifndef RF_PROBES_PER_ROUND
+#define RF_PROBES_PER_ROUND 8
+#endif
 
 struct rf_params {
     const uint32_t* table;            // [sO] half2 rows
@@ -285,8 +288,26 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 }
 
 // ---------------------------------------------------------------------------
-// render_frame: persistent waves, one ray per lane, ray queue in global memory
+// render_frame: one persistent 1024-thread workgroup per CU (16 waves, 1024 rays in flight), one ray per lane,
+// ray queue in global memory.  LDS per workgroup:
+//   [0, 36 KiB)        the 36 MFMA weight fragments of both networks, fragment-major (lane l reads 16 B at 16*l:
+//                      conflict-free ds_read_b128), so no weight occupies a VGPR and 4 waves fit per SIMD;
+//   [36 KiB, +C*4 KiB) coarse occupancy: one bit per 4x4x4 block of density-grid cells.  In Morton order such a
+//                      block is 64 consecutive bits = 8 consecutive bytes of the bitfield, so the coarse bit is
+//                      just "those 8 bytes != 0".  A probe whose block is empty never touches global memory:
+//                      the dependent global load leaves the march's critical path in empty space, and the decision
+//                      is identical to reading the fine bit (empty block => empty cell);
+//   [.., +16*2 KiB)    the 16 SH coefficients (half) of each lane's current ray, written once per ray.
 // ---------------------------------------------------------------------------
+
+static constexpr uint32_t RV_BLOCK = 256;
+#ifndef RV_BLOCKS_PER_CU
+#define RV_BLOCKS_PER_CU 2             // 216 VGPRs -> 2 waves per SIMD -> two 4-wave workgroups per CU (52 KiB LDS each)
+#endif
+static constexpr int RV_WAVES = RV_BLOCK / 64;
+static constexpr int RV_NFRAG = 36;
+static constexpr uint32_t RV_LDS_W = RV_NFRAG * 1024;                  // weight fragments
+static constexpr uint32_t RV_LDS_SH = RV_WAVES * 64 * 32;              // 16 halves per lane
 
 struct rf_frame {
     const float* rays_o; const float* rays_d; uint32_t N;
@@ -296,16 +317,170 @@ struct rf_frame {
     float bg[3];
     float* image; float* depth; float* weights_sum;
     uint32_t* stats; uint32_t* queue;
+    const uint32_t* coarse;          // [C * (H/4)^3 / 32] words, or null when H is not a power of two >= 4
+    uint32_t coarse_words;           // words per cascade level
+    uint32_t tile_w;                 // image width in pixels when the rays are a row-major image (8x8 tile order), else 0
 };
 
-__global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame F) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+// coarse[level][m] = any fine bit set in Morton block m (64 bits = 8 bytes of the bitfield)
+__global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict__ bitfield, uint32_t n_blocks_total,
+                                                      uint32_t* __restrict__ coarse) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;                 // one 32-bit word of coarse bits per thread
+    if (w * 32 >= n_blocks_total) return;
+    const uint64_t* b64 = reinterpret_cast<const uint64_t*>(bitfield);
+    uint32_t bits = 0;
+    #pragma unroll 8
+    for (uint32_t i = 0; i < 32; i++) {
+        const uint32_t blk = w * 32 + i;
+        if (blk < n_blocks_total && b64[blk] != 0ull) bits |= 1u << i;
+    }
+    coarse[w] = bits;
+}
+
+// ngp_march_t::probe with the coarse map in front of the fine bit (same arithmetic, same decisions)
+__device__ __forceinline__ bool rv_probe(const ngp_march_t& m, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
+                                         float& t, float& x, float& y, float& z, float& dt) {
+    const float tc = t;
+    x = ngp_clampf(m.ox + tc * m.dx, -m.bound, m.bound);
+    y = ngp_clampf(m.oy + tc * m.dy, -m.bound, m.bound);
+    z = ngp_clampf(m.oz + tc * m.dz, -m.bound, m.bound);
+    dt = ngp_clampf(tc * m.dt_gamma, m.dt_min, m.dt_max);
+    int e_pos, e_dt;
+    (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
+    (void)frexpf((dt * m.Hf) * 0.5f, &e_dt);
+    const int lp = m.mip(e_pos), ld = m.mip(e_dt);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf((float)(1 << level), m.bound);
+    const float mip_rbound = 1.0f / mip_bound;
+    const int nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
+    const int ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
+    const int nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
+    const uint32_t mort = ngp_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    bool occ;
+    bool maybe = true;
+    if (lds_coarse) {
+        const uint32_t blk = mort >> 6;
+        maybe = (lds_coarse[(uint32_t)level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u;
+    }
+    if (maybe) {
+        const uint32_t index = (uint32_t)((float)level * m.H3 + (float)mort);
+        occ = (m.grid[index >> 3] >> (index & 7u)) & 1u;
+    } else occ = false;
+    if (occ) return true;
+    const float tx = (((((float)nx + 0.5f + 0.5f * copysignf(1.0f, m.dx)) * m.rH) * 2.0f - 1.0f) * mip_bound - x) * m.rdx;
+    const float ty = (((((float)ny + 0.5f + 0.5f * copysignf(1.0f, m.dy)) * m.rH) * 2.0f - 1.0f) * mip_bound - y) * m.rdy;
+    const float tz = (((((float)nz + 0.5f + 0.5f * copysignf(1.0f, m.dz)) * m.rH) * 2.0f - 1.0f) * mip_bound - z) * m.rdz;
+    const float tt = tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    float tn = tc;
+    int guard = 0;
+    do {
+        tn += ngp_clampf(tn * m.dt_gamma, m.dt_min, m.dt_max);
+    } while (tn < tt && ++guard < NGP_SKIP_GUARD);
+    t = tn;
+    return false;
+}
+
+__device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int f, int lane) { return lds_w[f * 64 + lane]; }
+
+// rf_field_tile with the weights streamed from LDS and the SH coefficients of the column's ray read from LDS
+__device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w, int lane,
+                                              float px, float py, float pz, ngp_h4 shq,
+                                              float& sigma, float& cr, float& cg, float& cb) {
+    const ngp_h8 x = rf_encode(P, lv, px, py, pz);
+    const ngp_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    ngp_h8 act[2];
+    {
+        ngp_f4 d[MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(rv_frag(lds_w, t, lane), x, zero);
+        act[0] = mlp_pack_relu(d[0], d[1]);
+        act[1] = mlp_pack_relu(d[2], d[3]);
+    }
+    {
+        ngp_f4 d[MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) {
+            d[t] = ngp_mfma(rv_frag(lds_w, 4 + 2 * t, lane), act[0], zero);
+            d[t] = ngp_mfma(rv_frag(lds_w, 5 + 2 * t, lane), act[1], d[t]);
+        }
+        act[0] = mlp_pack_relu(d[0], d[1]);
+        act[1] = mlp_pack_relu(d[2], d[3]);
+    }
+    ngp_f4 h = ngp_mfma(rv_frag(lds_w, 12, lane), act[0], zero);
+    h = ngp_mfma(rv_frag(lds_w, 13, lane), act[1], h);
+
+    ngp_h8 cin;
+    #pragma unroll
+    for (int j = 0; j < 4; j++) { cin[j] = (_Float16)h[j]; cin[4 + j] = shq[j]; }
+    {
+        ngp_f4 d[MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(rv_frag(lds_w, 14 + t, lane), cin, zero);
+        act[0] = mlp_pack_relu(d[0], d[1]);
+        act[1] = mlp_pack_relu(d[2], d[3]);
+    }
+    #pragma unroll
+    for (int l = 0; l < 2; l++) {
+        ngp_f4 d[MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) {
+            d[t] = ngp_mfma(rv_frag(lds_w, 18 + 8 * l + 2 * t, lane), act[0], zero);
+            d[t] = ngp_mfma(rv_frag(lds_w, 19 + 8 * l + 2 * t, lane), act[1], d[t]);
+        }
+        act[0] = mlp_pack_relu(d[0], d[1]);
+        act[1] = mlp_pack_relu(d[2], d[3]);
+    }
+    ngp_f4 o = ngp_mfma(rv_frag(lds_w, 34, lane), act[0], zero);
+    o = ngp_mfma(rv_frag(lds_w, 35, lane), act[1], o);
+
+    sigma = P.density_scale * ngp_expf(rf_h(h[0]));
+    cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[0]))));
+    cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[1]))));
+    cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[2]))));
+}
+
+// queue index -> ray id.  With tile_w set (rays are a row-major image whose width and height are multiples of 8)
+// consecutive queue indices walk 8x8 pixel tiles, so the 64 lanes of a wave start on a compact patch of the image
+// and their gathers share cache lines; otherwise the identity.
+__device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w) {
+    if (tile_w == 0) return idx;
+    const uint32_t tile = idx >> 6, in = idx & 63u, tiles_x = tile_w >> 3;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    return (ty * 8 + (in >> 3)) * tile_w + tx * 8 + (in & 7u);
+}
+
+__global__ __launch_bounds__(RV_BLOCK) void k_render_frame(rf_params P, rf_frame F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
+    ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
+    _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
+    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH) : nullptr;
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
+
+    // ---- stage the weight fragments (each in the k order its consumer expects) and the coarse map ----
+    for (int f = wave; f < RV_NFRAG; f += RV_WAVES) {
+        ngp_h8 a;
+        const _Float16* Wc = P.w_color;
+        const _Float16* Wch = Wc + MLP_W * 32;
+        if (f < 4) a = mlp_load_a_natural(P.w_sigma, 32, 32, f, 0, lane);
+        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
+        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
+        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
+        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
+        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
+        lds_w[f * 64 + lane] = a;
+    }
+    if (lds_coarse) {
+        const uint32_t nw = F.coarse_words * F.C;
+        for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
+    }
+    __syncthreads();
+
     rf_lane_levels lv;
     rf_setup_levels(P, g, lv);
-    rf_weights W;
-    W.load(P, lane);
+    _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;                // this lane's ray
+    const _Float16* wave_sh = lds_sh + wave * 64 * 16;
 
-    // per-lane ray state
     bool active = false;
     uint32_t ray = 0, nsamp = 0;
     ngp_march_t m;
@@ -326,13 +501,17 @@ __global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame
                 if (!active) {
                     const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                     if (idx < F.N) {
-                        ray = idx;
-                        const float* o = F.rays_o + 3ull * idx;
-                        const float* d = F.rays_d + 3ull * idx;
+                        ray = rv_ray_of(idx, F.tile_w);
+                        const float* o = F.rays_o + 3ull * ray;
+                        const float* d = F.rays_d + 3ull * ray;
                         ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
                         m.setup(o, d, P.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.bitfield);
                         t = near; last_t = near; tcomp = near;
                         ws = 0; dacc = 0; cr = 0; cg = 0; cb = 0; nsamp = 0;
+                        float sh[16];
+                        sh_eval<4>(m.dx, m.dy, m.dz, P.shn, sh);      // the ray's direction encoding, once per ray
+                        #pragma unroll
+                        for (int j = 0; j < 16; j++) my_sh[j] = (_Float16)sh[j];
                         active = true;
                     }
                 }
@@ -341,12 +520,15 @@ __global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame
         }
         if (__ballot(active) == 0ull) break;            // queue drained and every ray of this wave is finished
 
-        // ---- march each active lane to its next occupied sample ----
-        bool has = false;
+        // ---- march each active lane towards its next occupied sample (bounded probes per round) ----
+        bool has = false, ended = false;
         float x = 0, y = 0, z = 0, dt = 0, d1 = 0;
         if (active) {
-            while (t < far && nsamp < F.max_steps) {
-                if (m.probe(t, x, y, z, dt)) { has = true; break; }
+            int probes = 0;
+            for (;;) {
+                if (!(t < far && nsamp < F.max_steps)) { ended = true; break; }
+                if (rv_probe(m, lds_coarse, F.coarse_words, t, x, y, z, dt)) { has = true; break; }
+                if (++probes >= RF_PROBES_PER_ROUND) break;
             }
             if (has) {
                 t += dt;
@@ -364,16 +546,15 @@ __global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame
             const bool v = __shfl((int)has, src, 64) != 0;
             if (__ballot(v) == 0ull) continue;           // wave-uniform: nothing to evaluate in this pass
             const float qx = __shfl(x, src, 64), qy = __shfl(y, src, 64), qz = __shfl(z, src, 64);
-            const float ex = __shfl(m.dx, src, 64), ey = __shfl(m.dy, src, 64), ez = __shfl(m.dz, src, 64);
+            const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             float a, b, c, d;
-            rf_field_tile(P, lv, W, g, qx, qy, qz, ex, ey, ez, a, b, c, d);
-            // results live in lanes 0..15 (g == 0); hand column s's result to lane 16p + s
+            rv_field_tile(P, lv, lds_w, lane, qx, qy, qz, shq, a, b, c, d);
             const float ra = __shfl(a, s, 64), rb = __shfl(b, s, 64), rc = __shfl(c, s, 64), rd = __shfl(d, s, 64);
             if (g == p) { sig = ra; sr = rb; sg = rc; sb = rd; }
         }
 
         // ---- composite (kernel_composite_rays arithmetic, raymarching.cu:865-896) ----
-        bool done = active && !has;                      // no further sample: t >= far or the sample cap
+        bool done = ended;
         if (has) {
             n_samples_local++;
             const float alpha = 1.0f - ngp_expf(-sig * dt);
@@ -386,8 +567,7 @@ __global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame
             if ((double)T < 1e-4) done = true;
         }
         if (done) {
-            // nerf/renderer.py:371-372
-            F.image[3ull * ray] = cr + (1 - ws) * F.bg[0];
+            F.image[3ull * ray] = cr + (1 - ws) * F.bg[0];           // nerf/renderer.py:371-372
             F.image[3ull * ray + 1] = cg + (1 - ws) * F.bg[1];
             F.image[3ull * ray + 2] = cb + (1 - ws) * F.bg[2];
             F.depth[ray] = fmaxf(dacc - near, 0.0f) / (far - near);
@@ -397,17 +577,21 @@ __global__ __launch_bounds__(RF_BLOCK) void k_render_frame(rf_params P, rf_frame
             active = false;
         }
     }
-    // one atomic per wave for the sample count
     uint32_t tot = n_samples_local;
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(F.stats, tot);
 }
 
-extern "C" size_t ngp_render_frame_workspace(uint32_t N) { (void)N; return 64; }
+static inline bool rv_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+extern "C" size_t ngp_render_frame_workspace(uint32_t N) {
+    (void)N;
+    return 64 + 48 * 1024;                                             // ray queue + coarse occupancy map (<= 48 KiB)
+}
 
 extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
-                                const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                                uint32_t image_width, const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
                                 float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
                                 float* image, float* depth, float* weights_sum, uint32_t* stats,
                                 void* workspace, size_t workspace_bytes, void* stream) {
@@ -430,11 +614,35 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     for (int i = 0; i < 3; i++) F.bg[i] = bg_color3_host[i];
     F.image = image; F.depth = depth; F.weights_sum = weights_sum;
     F.stats = stats; F.queue = (uint32_t*)workspace;
-    // persistent grid: 2 workgroups (8 waves, 512 rays in flight) per CU, fewer when the frame is small
-    uint32_t blocks = 256 * 2;
-    const uint32_t need = ngp_div_up(N, RF_BLOCK);
+    F.tile_w = 0;
+    const uint32_t hint = image_width;
+    if (hint >= 8 && hint % 8 == 0 && N % hint == 0 && (N / hint) % 8 == 0) F.tile_w = hint;
+
+    // coarse occupancy (needs Morton blocks: H a power of two >= 4) in the workspace, then in LDS
+    F.coarse = nullptr; F.coarse_words = 0;
+    size_t lds = RV_LDS_W + RV_LDS_SH;
+    const uint64_t blocks_per_level = (uint64_t)Hgrid * Hgrid * Hgrid / 64;
+    const uint64_t coarse_bytes = (uint64_t)C * blocks_per_level / 8;
+    if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && coarse_bytes <= 48 * 1024 &&
+        workspace_bytes >= 64 + coarse_bytes && (reinterpret_cast<uintptr_t>(bitfield) & 7u) == 0) {
+        uint32_t* coarse = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + 64);
+        const uint32_t n_blocks_total = (uint32_t)(C * blocks_per_level);
+        hipLaunchKernelGGL(k_build_coarse, dim3(ngp_div_up(n_blocks_total / 32, 256)), dim3(256), 0, s, bitfield, n_blocks_total, coarse);
+        F.coarse = coarse;
+        F.coarse_words = (uint32_t)(blocks_per_level / 32);
+        lds += coarse_bytes;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_frame), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return ngp_fail(NGP_ELAUNCH, "render_frame: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    // persistent grid: RV_BLOCKS_PER_CU workgroups per CU, fewer when the frame is small
+    uint32_t blocks = 256 * RV_BLOCKS_PER_CU;
+    const uint32_t need = ngp_div_up(N, RV_BLOCK);
     if (blocks > need) blocks = need;
-    hipLaunchKernelGGL(k_render_frame, dim3(blocks), dim3(RF_BLOCK), 0, s, P, F);
+    hipLaunchKernelGGL(k_render_frame, dim3(blocks), dim3(RV_BLOCK), lds, s, P, F);
     NGP_CHECK_LAUNCH("render_frame");
     return NGP_OK;
 }

@@ -128,9 +128,10 @@ class NGPRenderer(nn.Module):
     # one launch per frame
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def render_fused(self, rays_o, rays_d, dt_gamma=0, bg_color=None, max_steps=1024, **kwargs):
+    def render_fused(self, rays_o, rays_d, dt_gamma=0, bg_color=None, max_steps=1024, image_width=0, **kwargs):
         """Inference only.  Returns image / depth / weights_sum like run_cuda plus `stats`, a 4-int device tensor:
-        [ray-samples evaluated, rays that hit the max_steps cap, rays with >= 1 sample, 0]."""
+        [ray-samples evaluated, rays that hit the max_steps cap, rays with >= 1 sample, 0].
+        image_width: width of the image when the rays are a full row-major image (enables 8x8 tile traversal)."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -146,7 +147,7 @@ class NGPRenderer(nn.Module):
         L = _hip.lib()
         ws = _hip.workspace(L.ngp_render_frame_workspace(N), device)
         f = self.field.fused_state()
-        _hip.check(L.ngp_render_frame(ctypes.byref(f), _hip.ptr(rays_o), _hip.ptr(rays_d), N, aabb, self.min_near,
+        _hip.check(L.ngp_render_frame(ctypes.byref(f), _hip.ptr(rays_o), _hip.ptr(rays_d), N, int(image_width), aabb, self.min_near,
                                       _hip.ptr(self.density_bitfield), self.cascade, self.grid_size, dt_gamma, max_steps, bg,
                                       _hip.ptr(image), _hip.ptr(depth), _hip.ptr(weights_sum), _hip.ptr(stats),
                                       _hip.ptr(ws), ws.numel(), _hip.stream()), "render_frame")
