@@ -29,7 +29,7 @@
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
 #ifndef RF_PROBES_PER_ROUND
-#define RF_PROBES_PER_ROUND 8
+#define RF_PROBES_PER_ROUND 32         // A/B on MI355X (800x800 S-ring): 4: 26.0 ms, 8: 19.9, 16: 12.5, 32: 12.2, 48: 12.6
 #endif
 
 struct rf_params {
@@ -300,14 +300,19 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 //   [.., +16*2 KiB)    the 16 SH coefficients (half) of each lane's current ray, written once per ray.
 // ---------------------------------------------------------------------------
 
-static constexpr uint32_t RV_BLOCK = 256;
-#ifndef RV_BLOCKS_PER_CU
-#define RV_BLOCKS_PER_CU 2             // 216 VGPRs -> 2 waves per SIMD -> two 4-wave workgroups per CU (52 KiB LDS each)
+#ifndef RV_BLOCK_THREADS
+#define RV_BLOCK_THREADS 256
 #endif
+#ifndef RV_BLOCKS_PER_CU
+#define RV_BLOCKS_PER_CU 3             // 164 VGPRs -> 3 waves per SIMD -> three 4-wave workgroups per CU (53 KiB LDS each)
+#endif
+static constexpr uint32_t RV_BLOCK = RV_BLOCK_THREADS;
+static constexpr int RV_WAVES_PER_SIMD = (RV_BLOCK_THREADS / 256) * RV_BLOCKS_PER_CU;
 static constexpr int RV_WAVES = RV_BLOCK / 64;
 static constexpr int RV_NFRAG = 36;
 static constexpr uint32_t RV_LDS_W = RV_NFRAG * 1024;                  // weight fragments
 static constexpr uint32_t RV_LDS_SH = RV_WAVES * 64 * 32;              // 16 halves per lane
+static constexpr uint32_t RV_LDS_LV = 4 * 96;                          // rf_lane_levels of the 4 lane groups
 
 struct rf_frame {
     const float* rays_o; const float* rays_d; uint32_t N;
@@ -337,9 +342,21 @@ __global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict_
     coarse[w] = bits;
 }
 
+// The march state of ngp_march_t split in two so that only what differs per ray occupies VGPRs:
+struct rv_ray { float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz; };
+struct rv_consts {                                     // wave-uniform (SGPRs), same formulas as ngp_march_t::setup
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
+    const uint8_t* grid;
+    __device__ __forceinline__ int mip(int e) const { return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e)); }
+};
+struct rv_view : rv_ray, rv_consts {                   // what rv_probe reads: per-ray VGPRs + uniform SGPRs
+    __device__ __forceinline__ rv_view(const rv_ray& r, const rv_consts& k) : rv_ray(r), rv_consts(k) {}
+};
+
 // ngp_march_t::probe with the coarse map in front of the fine bit (same arithmetic, same decisions)
-__device__ __forceinline__ bool rv_probe(const ngp_march_t& m, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
+__device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
                                          float& t, float& x, float& y, float& z, float& dt) {
+    const rv_view m(ray, k);
     const float tc = t;
     x = ngp_clampf(m.ox + tc * m.dx, -m.bound, m.bound);
     y = ngp_clampf(m.oy + tc * m.dy, -m.bound, m.bound);
@@ -449,11 +466,11 @@ __device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w) {
     return (ty * 8 + (in >> 3)) * tile_w + tx * 8 + (in & 7u);
 }
 
-__global__ __launch_bounds__(RV_BLOCK) void k_render_frame(rf_params P, rf_frame F) {
+__global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf_params P, rf_frame F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
     _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
-    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH) : nullptr;
+    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV) : nullptr;
 
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
 
@@ -474,16 +491,31 @@ __global__ __launch_bounds__(RV_BLOCK) void k_render_frame(rf_params P, rf_frame
         const uint32_t nw = F.coarse_words * F.C;
         for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
     }
+    // per-lane-group level constants live in LDS (re-read in each pass) instead of 24 VGPRs across the march loop
+    rf_lane_levels* lds_lv = reinterpret_cast<rf_lane_levels*>(rv_smem + RV_LDS_W + RV_LDS_SH);
+    if (wave == 0 && s == 0) {
+        rf_lane_levels tmp;
+        rf_setup_levels(P, g, tmp);
+        lds_lv[g] = tmp;
+    }
     __syncthreads();
 
-    rf_lane_levels lv;
-    rf_setup_levels(P, g, lv);
     _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;                // this lane's ray
     const _Float16* wave_sh = lds_sh + wave * 64 * 16;
 
+    // wave-uniform march constants (ngp_march_t::setup's formulas), kept out of the per-ray state
+    rv_consts K;
+    K.bound = P.bound; K.dt_gamma = F.dt_gamma;
+    K.Hf = (float)F.H; K.Cf = (float)F.C; K.Hm1 = (float)(F.H - 1);
+    K.rH = 1.0f / K.Hf;
+    K.H3 = (float)(F.H * F.H * F.H);
+    K.dt_min = (2.0f * 1.7320508075688772f) / (float)F.max_steps;
+    K.dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf;
+    K.grid = F.bitfield;
+
     bool active = false;
     uint32_t ray = 0, nsamp = 0;
-    ngp_march_t m;
+    rv_ray m;
     float t = 0, last_t = 0, near = 0, far = 0;
     float ws = 0, dacc = 0, cr = 0, cg = 0, cb = 0, tcomp = 0;
     bool exhausted = false;
@@ -505,7 +537,9 @@ __global__ __launch_bounds__(RV_BLOCK) void k_render_frame(rf_params P, rf_frame
                         const float* o = F.rays_o + 3ull * ray;
                         const float* d = F.rays_d + 3ull * ray;
                         ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
-                        m.setup(o, d, P.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.bitfield);
+                        m.ox = o[0]; m.oy = o[1]; m.oz = o[2];
+                        m.dx = d[0]; m.dy = d[1]; m.dz = d[2];
+                        m.rdx = 1.0f / m.dx; m.rdy = 1.0f / m.dy; m.rdz = 1.0f / m.dz;
                         t = near; last_t = near; tcomp = near;
                         ws = 0; dacc = 0; cr = 0; cg = 0; cb = 0; nsamp = 0;
                         float sh[16];
@@ -527,7 +561,7 @@ __global__ __launch_bounds__(RV_BLOCK) void k_render_frame(rf_params P, rf_frame
             int probes = 0;
             for (;;) {
                 if (!(t < far && nsamp < F.max_steps)) { ended = true; break; }
-                if (rv_probe(m, lds_coarse, F.coarse_words, t, x, y, z, dt)) { has = true; break; }
+                if (rv_probe(m, K, lds_coarse, F.coarse_words, t, x, y, z, dt)) { has = true; break; }
                 if (++probes >= RF_PROBES_PER_ROUND) break;
             }
             if (has) {
@@ -548,6 +582,7 @@ __global__ __launch_bounds__(RV_BLOCK) void k_render_frame(rf_params P, rf_frame
             const float qx = __shfl(x, src, 64), qy = __shfl(y, src, 64), qz = __shfl(z, src, 64);
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             float a, b, c, d;
+            const rf_lane_levels lv = lds_lv[g];
             rv_field_tile(P, lv, lds_w, lane, qx, qy, qz, shq, a, b, c, d);
             const float ra = __shfl(a, s, 64), rb = __shfl(b, s, 64), rc = __shfl(c, s, 64), rd = __shfl(d, s, 64);
             if (g == p) { sig = ra; sr = rb; sg = rc; sb = rd; }
@@ -620,7 +655,8 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
 
     // coarse occupancy (needs Morton blocks: H a power of two >= 4) in the workspace, then in LDS
     F.coarse = nullptr; F.coarse_words = 0;
-    size_t lds = RV_LDS_W + RV_LDS_SH;
+    static_assert(sizeof(rf_lane_levels) * 4 == RV_LDS_LV, "LDS carve of the level table");
+    size_t lds = RV_LDS_W + RV_LDS_SH + RV_LDS_LV;
     const uint64_t blocks_per_level = (uint64_t)Hgrid * Hgrid * Hgrid / 64;
     const uint64_t coarse_bytes = (uint64_t)C * blocks_per_level / 8;
     if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && coarse_bytes <= 48 * 1024 &&

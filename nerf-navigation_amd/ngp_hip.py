@@ -11,7 +11,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libngp_hip.so")
+# NGP_HIP_LIB selects another build of the SAME library (A/B runs of kernel variants); it is never a fallback
+LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "lib", "libngp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, F16 = 0, 1
