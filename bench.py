@@ -66,9 +66,10 @@ def main():
     intr = W.intrinsics(H, Wd)
     n_poses = 8
     # every rank walks the same orbit, phase-shifted by its rank, so ranks never render the same view at the same step
+    from ngp import sharding
     rays = []
-    for k in range(n_poses):
-        o, d = W.get_rays(W.orbit_pose((k * world + rank) % (n_poses * world), n_poses * world), intr, H, Wd)
+    for view in sharding.pose_indices(rank, world, n_poses):
+        o, d = W.get_rays(W.orbit_pose(view, n_poses * world), intr, H, Wd)
         rays.append((torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]))
     N = H * Wd
 
@@ -111,15 +112,7 @@ def main():
         samples = sum(per_pose[k % n_poses] for k in range(args.steps))
         capped = 0
 
-    tot = torch.tensor([float(samples), elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        t_max = tot[1:2].clone()
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        s_sum = tot[0:1].clone()
-        dist.all_reduce(s_sum, op=dist.ReduceOp.SUM)
-        elapsed_max, samples_all = float(t_max.item()), float(s_sum.item())
-    else:
-        elapsed_max, samples_all = elapsed, float(samples)
+    samples_all, elapsed_max = sharding.reduce_throughput(samples, elapsed, dev)   # sum of samples, max of wall time
 
     if rank != 0:
         if world > 1:
@@ -167,6 +160,22 @@ def main():
             "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,
         },
     }
+
+    # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the figure comes from the
+    # committed rocprofv3 --pmc passes of THIS command (tools/profile_round.sh -> profiles/<tag>_pmc.csv):
+    # (FETCH_SIZE + WRITE_SIZE) KiB.  The loads are 4-byte scattered gathers, so the guide's 2x correction for wide
+    # coalesced streams does not apply (FETCH_SIZE == TCC_EA0_RDREQ x 64 B in the same profile).
+    try:
+        import csv
+        import glob
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))[-1]
+        c = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(pmc))}
+        if args.path == "fused" and args.res == 800:
+            result["roofline"]["traffic"] = (c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
+            result["roofline"]["traffic_unit"] = "bytes per launch (L2-miss / fabric side; table is Infinity-Cache resident)"
+            result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
+    except (IndexError, KeyError, OSError):
+        pass
 
     if not args.no_cpu and world == 1:
         from oracle import ngp_oracle as O, render_oracle as R
