@@ -682,10 +682,3 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     NGP_CHECK_LAUNCH("render_frame");
     return NGP_OK;
 }
-
-// placeholder until the training path lands (ffmlp backward)
-extern "C" size_t ngp_ffmlp_backward_workspace(uint32_t, uint32_t, uint32_t, uint32_t) { return 16; }
-extern "C" int ngp_ffmlp_backward(const void*, const void*, const void*, const void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                                  uint32_t, uint32_t, int, void*, void*, void*, void*, size_t, void*) {
-    return ngp_fail(NGP_EINVAL, "ffmlp_backward: not built");
-}

@@ -84,3 +84,77 @@ def test_ffmlp_rejects_unsupported(dev):
     z = torch.zeros(4096, dtype=torch.float16, device=dev)
     rc = ngp_hip.lib().ngp_ffmlp_inference(ngp_hip.ptr(z), ngp_hip.ptr(z), 16, 32, 16, 128, 2, 0, 6, None, ngp_hip.ptr(z), ngp_hip.stream())
     assert rc == -1 and b"hidden_dim" in ngp_hip.lib().ngp_last_error()
+
+
+def run_hip_backward(dev, g, x, w, fb, input_dim, num_layers, calc):
+    import ngp_hip
+    B = x.shape[0]
+    L = ngp_hip.lib()
+    tg, tx, tw, tfb = t(g, dev), t(x, dev), t(w, dev), t(fb, dev)
+    bb = torch.zeros(num_layers, B, 64, dtype=torch.float16, device=dev)
+    gi = torch.zeros(B, input_dim, dtype=torch.float16, device=dev)
+    gw = torch.zeros(w.shape[0], dtype=torch.float16, device=dev)
+    ws = ngp_hip.workspace(L.ngp_ffmlp_backward_workspace(input_dim, 16, 64, num_layers), dev)
+    ngp_hip.check(L.ngp_ffmlp_backward(ngp_hip.ptr(tg), ngp_hip.ptr(tx), ngp_hip.ptr(tw), ngp_hip.ptr(tfb), B, input_dim, 16, 64, num_layers,
+                                       0, 6, int(calc), ngp_hip.ptr(bb), ngp_hip.ptr(gi), ngp_hip.ptr(gw), ngp_hip.ptr(ws), ws.numel(),
+                                       ngp_hip.stream()))
+    return gw.cpu().numpy(), gi.cpu().numpy(), bb.cpu().numpy()
+
+
+@pytest.mark.parametrize("input_dim,num_layers", [(32, 2), (32, 3), (64, 2), (16, 2), (48, 4)])
+def test_ffmlp_backward_exact_integer_data(oracle, dev, input_dim, num_layers):
+    """small-integer data: every product and partial sum is exact in half/f32, so the transposed weight fragments, the
+    ReLU masks, the LDS transposes of the weight-gradient GEMMs and the atomics must reproduce the oracle exactly"""
+    rng = np.random.default_rng(100 + input_dim + num_layers)
+    B = 128 if num_layers < 4 else 32                          # keep every gradient below 2048 (exact in half)
+    nw = oracle.ffmlp_num_params(input_dim, 16, 64, num_layers)
+    w = rng.choice([-1.0, 0, 0, 0, 0, 0, 0, 1.0], size=nw).astype(np.float16)
+    x = rng.integers(0, 2, size=(B, input_dim)).astype(np.float16)
+    g = rng.choice([-1.0, 0, 0, 1.0], size=(B, 16)).astype(np.float16)
+    _, fb = oracle.ffmlp_forward(x, w, input_dim, 16, 64, num_layers, save=True)
+    gw_ref, gi_ref, bb_ref = oracle.ffmlp_backward(g, x, w, fb, input_dim, 16, 64, num_layers, True)
+    assert np.abs(gw_ref).max() < 2048 and np.abs(gi_ref).max() < 2048 and np.abs(bb_ref.astype(np.float32)).max() < 2048
+    assert np.abs(gw_ref).max() > 8 and (bb_ref != 0).mean() > 0.05
+    gw, gi, bb = run_hip_backward(dev, g, x, w, fb, input_dim, num_layers, True)
+    assert np.array_equal(bb.view(np.uint16), bb_ref.view(np.uint16)), "backward_buffer"
+    assert np.array_equal(gi.astype(np.float32), gi_ref), "grad_inputs"
+    assert np.array_equal(gw.astype(np.float32), gw_ref), "grad_weights"
+
+
+def test_ffmlp_backward_random_data_tolerance(oracle, dev):
+    rng = np.random.default_rng(7)
+    input_dim, num_layers, B = 32, 3, 128 * 40
+    nw = oracle.ffmlp_num_params(input_dim, 16, 64, num_layers)
+    w = rng.uniform(-np.sqrt(3 / 64), np.sqrt(3 / 64), size=nw).astype(np.float16)
+    x = rng.normal(size=(B, input_dim)).astype(np.float16)
+    g = (rng.normal(size=(B, 16)) * 1e-2).astype(np.float16)
+    _, fb = oracle.ffmlp_forward(x, w, input_dim, 16, 64, num_layers, save=True)
+    gw_ref, gi_ref, bb_ref = oracle.ffmlp_backward(g, x, w, fb, input_dim, 16, 64, num_layers, True)
+    gw, gi, bb = run_hip_backward(dev, g, x, w, fb, input_dim, num_layers, True)
+    # activation gradients are halves: one half ulp per layer, amplified by the next layers
+    s = np.abs(bb_ref.astype(np.float32)).max()
+    assert np.max(np.abs(bb.astype(np.float32) - bb_ref.astype(np.float32))) < 4e-3 * s
+    assert np.max(np.abs(gi.astype(np.float32) - gi_ref)) < 6e-3 * np.abs(gi_ref).max()
+    # weight gradients: f32 MFMA accumulation over 5120 samples, rounded to half once (the reference accumulates in half)
+    assert np.max(np.abs(gw.astype(np.float32) - gw_ref)) < 4e-3 * np.abs(gw_ref).max()
+
+
+def test_ffmlp_module_autograd(oracle, dev):
+    from ffmlp import FFMLP
+    net = FFMLP(32, 16, 64, 2).to(dev).train()
+    w = net.weights.detach().cpu().numpy().astype(np.float16)
+    rng = np.random.default_rng(3)
+    B = 300                                                    # padded to 384 inside FFMLP.forward
+    x = rng.normal(size=(B, 32)).astype(np.float32)
+    g = (rng.normal(size=(B, 16)) * 1e-2).astype(np.float32)
+    xt = t(x, dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(xt)
+    y.backward(t(g, dev).half())
+    assert net.weights.grad.dtype == torch.float32 and xt.grad.shape == (B, 32)
+    xp = np.concatenate([x.astype(np.float16), np.zeros((84, 32), np.float16)])
+    gp = np.concatenate([g.astype(np.float16), np.zeros((84, 16), np.float16)])
+    _, fb = oracle.ffmlp_forward(xp, w, 32, 16, 64, 2, save=True)
+    gw_ref, gi_ref, _ = oracle.ffmlp_backward(gp, xp, w, fb, 32, 16, 64, 2, True)
+    assert np.max(np.abs(net.weights.grad.cpu().numpy() - gw_ref)) < 4e-3 * np.abs(gw_ref).max()
+    assert np.max(np.abs(xt.grad.cpu().numpy() - gi_ref[:B])) < 6e-3 * np.abs(gi_ref).max()
