@@ -162,3 +162,41 @@ def test_encoder_backward_is_constant_under_create_graph(dev):
     x0 = (torch.rand(4, 3, device=dev) * 2 - 1)
     H = torch.autograd.functional.hessian(lambda p: enc(p, bound=1).pow(2).sum(), x0)
     assert H.shape == (4, 3, 4, 3) and float(H.abs().max()) == 0.0
+
+
+def test_trainer_fits_the_scene(scene, dev):
+    """config 3 end to end: train a freshly initialised FFMLP field on views of the S-ring scene rendered by the
+    hand-set model (the ground truth here), with the reference's recipe; PSNR on a held-out view must rise clearly."""
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    from ngp.train import NGPTrainer
+    from oracle import render_oracle as R
+    W = scene["W"]
+    teacher = make(scene, dev, True).eval()
+    res, intr = 64, W.intrinsics(64, 64)
+    pool_o, pool_d, pool_c = [], [], []
+    for k in range(12):
+        o, d = W.get_rays(W.orbit_pose(k, 12), intr, res, res)
+        to, td = t(o, dev)[None], t(d, dev)[None]
+        pool_o.append(to); pool_d.append(td)
+        pool_c.append(teacher.render_fused(to, td, bg_color=1)["image"])
+    held = 5
+    torch.manual_seed(0)
+    student = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
+    tr = NGPTrainer(student, lr=1e-2, iters=400, fp16=True)
+
+    def psnr():
+        with torch.no_grad():
+            img = student.eval().render_fused(pool_o[held], pool_d[held], bg_color=1)["image"]
+        return R.psnr(img.cpu().numpy(), pool_c[held].cpu().numpy())
+
+    views = [k for k in range(12) if k != held]
+    p0 = None
+    for it in range(160):
+        k = views[it % len(views)]
+        loss = tr.step(pool_o[k], pool_d[k], pool_c[k], bg_color=1, max_steps=1024)
+        if it == 0:
+            p0 = psnr()
+    p1 = psnr()
+    assert torch.isfinite(loss) and student.mean_count > 0 and student.iter_density == 10
+    assert p1 > p0 + 3.0 and p1 > 15.0, (p0, p1)
