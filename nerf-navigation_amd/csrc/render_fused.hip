@@ -115,8 +115,27 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
             }
         }
         const uint32_t* tab = P.table + lv.base[i];
+#if RV_PAIR_LOADS
+        // The two x-neighbours of a (y,z) pair often sit in one aligned 8-byte pair of rows (dense level with an even
+        // row, hashed level with an even x: x ^ K and (x+1) ^ K then differ in bit 0 only): one 8-byte load instead of
+        // two 4-byte loads, i.e. fewer L1 requests for the same bytes.
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i0 = idx[2 * q], i1 = idx[2 * q + 1];
+            if (oob) { raw[i][2 * q] = 0u; raw[i][2 * q + 1] = 0u; }
+            else if ((i0 ^ i1) == 1u) {
+                const uint2 v = *reinterpret_cast<const uint2*>(tab + (i0 & ~1u));
+                raw[i][2 * q] = (i0 & 1u) ? v.y : v.x;
+                raw[i][2 * q + 1] = (i0 & 1u) ? v.x : v.y;
+            } else {
+                raw[i][2 * q] = tab[i0];
+                raw[i][2 * q + 1] = tab[i1];
+            }
+        }
+#else
         #pragma unroll
         for (int c = 0; c < 8; c++) raw[i][c] = oob ? 0u : tab[idx[c]];
+#endif
     }
     ngp_h8 out;
     #pragma unroll
@@ -300,11 +319,20 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 //   [.., +16*2 KiB)    the 16 SH coefficients (half) of each lane's current ray, written once per ray.
 // ---------------------------------------------------------------------------
 
+// Tuning knobs, each A/B-measured on MI355X with tools/ab_variants.sh (800x800 S-ring frame, ms per frame):
+//   256 thr x 2/CU (2 waves/SIMD) 16.8 | 256 x 3 (3 waves/SIMD, 164 VGPR) 12.2 | + paired loads (136 VGPR) 10.5
+//   | 512 x 2 (4 waves/SIMD, 128 VGPR, 24 B/lane scratch) 9.2 | + 4x4 patches 9.1
 #ifndef RV_BLOCK_THREADS
-#define RV_BLOCK_THREADS 256
+#define RV_BLOCK_THREADS 512
 #endif
 #ifndef RV_BLOCKS_PER_CU
-#define RV_BLOCKS_PER_CU 3             // 164 VGPRs -> 3 waves per SIMD -> three 4-wave workgroups per CU (53 KiB LDS each)
+#define RV_BLOCKS_PER_CU 2             // two 8-wave workgroups per CU = 4 waves per SIMD, 62 KiB LDS each
+#endif
+#ifndef RV_PAIR_LOADS
+#define RV_PAIR_LOADS 1                // 8-byte loads for x-neighbour pairs that share an aligned row pair
+#endif
+#ifndef RV_PATCH_4X4
+#define RV_PATCH_4X4 1                 // each 16-lane column group covers a 4x4 pixel patch
 #endif
 static constexpr uint32_t RV_BLOCK = RV_BLOCK_THREADS;
 static constexpr int RV_WAVES_PER_SIMD = (RV_BLOCK_THREADS / 256) * RV_BLOCKS_PER_CU;
@@ -463,7 +491,14 @@ __device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w) {
     if (tile_w == 0) return idx;
     const uint32_t tile = idx >> 6, in = idx & 63u, tiles_x = tile_w >> 3;
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+#if RV_PATCH_4X4
+    // lanes 16p..16p+15 (one MFMA column tile, one gather instruction group) cover a compact 4x4 pixel patch
+    const uint32_t p = in >> 4, s = in & 15u;
+    const uint32_t px = (p & 1u) * 4 + (s & 3u), py = (p >> 1) * 4 + (s >> 2);
+    return (ty * 8 + py) * tile_w + tx * 8 + px;
+#else
     return (ty * 8 + (in >> 3)) * tile_w + tx * 8 + (in & 7u);
+#endif
 }
 
 __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf_params P, rf_frame F) {
@@ -579,7 +614,12 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
             const int src = 16 * p + s;
             const bool v = __shfl((int)has, src, 64) != 0;
             if (__ballot(v) == 0ull) continue;           // wave-uniform: nothing to evaluate in this pass
+#ifdef RV_EXPERIMENT_SAMEPOS       // timing-only build: columns share positions in groups of RV_EXPERIMENT_SAMEPOS
+            const int psrc = 16 * p + (s & ~(RV_EXPERIMENT_SAMEPOS - 1));
+            const float qx = __shfl(x, psrc, 64), qy = __shfl(y, psrc, 64), qz = __shfl(z, psrc, 64);
+#else
             const float qx = __shfl(x, src, 64), qy = __shfl(y, src, 64), qz = __shfl(z, src, 64);
+#endif
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             float a, b, c, d;
             const rf_lane_levels lv = lds_lv[g];
