@@ -123,6 +123,9 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
         for (int q = 0; q < 4; q++) {
             const uint32_t i0 = idx[2 * q], i1 = idx[2 * q + 1];
             if (oob) { raw[i][2 * q] = 0u; raw[i][2 * q + 1] = 0u; }
+#ifdef RV_EXPERIMENT_NOLOADS       // timing-only build: what the kernel costs without its table gathers
+            else if (true) { raw[i][2 * q] = i0 * 0x9E3779B1u; raw[i][2 * q + 1] = i1 * 0x9E3779B1u; }
+#endif
             else if ((i0 ^ i1) == 1u) {
                 const uint2 v = *reinterpret_cast<const uint2*>(tab + (i0 & ~1u));
                 raw[i][2 * q] = (i0 & 1u) ? v.y : v.x;
