@@ -56,14 +56,17 @@ __device__ __forceinline__ ngp_h8 mlp_load_a_permuted(const _Float16* __restrict
 }
 
 // ReLU + round-to-half of two D tiles -> one B fragment of the next layer (k-step c = tiles 2c, 2c+1)
+// (round first, then ReLU on packed halves: rounding is monotone and sign-preserving, so half(max(x,0)) == max(half(x),0)
+//  bit for bit, and it is 4 v_cvt_pk + 4 v_pk_max instead of 8 v_max + 4 v_cvt_pk)
 __device__ __forceinline__ ngp_h8 mlp_pack_relu(ngp_f4 d0, ngp_f4 d1) {
     ngp_h8 b;
     #pragma unroll
     for (int r = 0; r < 4; r++) {
-        b[r] = (_Float16)fmaxf(d0[r], 0.0f);
-        b[4 + r] = (_Float16)fmaxf(d1[r], 0.0f);
+        b[r] = (_Float16)d0[r];
+        b[4 + r] = (_Float16)d1[r];
     }
-    return b;
+    const ngp_h8 zero = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    return __builtin_elementwise_max(b, zero);
 }
 
 // The weights of one network held in registers.  NHID = number of hidden (64x64) matmuls = num_layers - 1,

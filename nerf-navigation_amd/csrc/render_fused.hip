@@ -26,6 +26,14 @@
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 
+// knobs of the encoder (used by rf_encode below, so they are defined first)
+#ifndef RV_PAIR_LOADS
+#define RV_PAIR_LOADS 1                // 8-byte loads for x-neighbour pairs that share an aligned row pair
+#endif
+#ifndef RF_LEVEL_BATCH
+#define RF_LEVEL_BATCH 4               // levels gathered before blending (1, 2 or 4)
+#endif
+
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
 #ifndef RF_PROBES_PER_ROUND
@@ -38,6 +46,7 @@ struct rf_params {
     const _Float16* w_sigma;          // 64*(32+64+16)
     const _Float16* w_color;          // 64*(32+128+16)
     float bound, density_scale;
+    float inv_b2;                     // 1 / (2 bound) when that is exact (2 bound a power of two), else 0
     float scale[RF_L];                // exp2f(l*S)*H - 1 (host)
     uint32_t resolution[RF_L];        // ceil(scale)+1
     sh_norm shn;
@@ -84,13 +93,22 @@ __device__ __forceinline__ float rf_h(float v) { return (float)(_Float16)v; }   
 // Hash-grid encoding of one sample for the 4 levels of this lane's group -> 8 half features (k = 8g + 2i + ch).
 // Arithmetic identical, operation for operation, to k_grid_forward<_Float16,3,2> (gridencoder.hip).
 __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, float wx, float wy, float wz) {
+    // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound).  When 2*bound is a power of two (every cascade-aligned
+    // bound) the quotient equals the product with the exact reciprocal, bit for bit, and skips three IEEE divisions.
     const float b2 = 2 * P.bound;
-    const float x0 = (wx + P.bound) / b2, x1 = (wy + P.bound) / b2, x2 = (wz + P.bound) / b2;   // GridEncoder.forward (grid.py:144)
+    float x0, x1, x2;
+    if (P.inv_b2 != 0.0f) { x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2; }
+    else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
     const bool oob = (x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1);
+    // RF_LEVEL_BATCH levels are gathered (all their loads in flight) before they are blended.  4 = maximum memory-level
+    // parallelism, 2 = 16 fewer live VGPRs: the kernel is issue-bound, not latency-bound, at 4 waves per SIMD.
+    ngp_h8 out;
+    #pragma unroll
+    for (int b0 = 0; b0 < 4; b0 += RF_LEVEL_BATCH) {
     uint32_t raw[4][8];
     float fx[4], fy[4], fz[4];
     #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = b0; i < b0 + RF_LEVEL_BATCH; i++) {
         const float sc = lv.scale[i];
         float px = x0 * sc + 0.5f, py = x1 * sc + 0.5f, pz = x2 * sc + 0.5f;
         const uint32_t gx = (uint32_t)floorf(px), gy = (uint32_t)floorf(py), gz = (uint32_t)floorf(pz);
@@ -140,9 +158,8 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
         for (int c = 0; c < 8; c++) raw[i][c] = oob ? 0u : tab[idx[c]];
 #endif
     }
-    ngp_h8 out;
     #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = b0; i < b0 + RF_LEVEL_BATCH; i++) {
         float r0 = 0.0f, r1 = 0.0f;
         #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -156,6 +173,8 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
         }
         out[2 * i] = (_Float16)r0;
         out[2 * i + 1] = (_Float16)r1;
+    }
+    if (b0 + RF_LEVEL_BATCH < 4) __builtin_amdgcn_sched_barrier(0);    // keep the next batch's loads below this point
     }
     if (oob) {
         #pragma unroll
@@ -286,6 +305,11 @@ static int rf_fill_params(const char* who, const ngp_field_t* f, rf_params& P) {
     P.w_color = (const _Float16*)f->color_weights;
     P.bound = f->bound;
     P.density_scale = f->density_scale;
+    {
+        int e;
+        const float b2 = 2.0f * f->bound;
+        P.inv_b2 = (frexpf(b2, &e) == 0.5f) ? 1.0f / b2 : 0.0f;
+    }
     for (int l = 0; l < RF_L; l++) {
         P.scale[l] = exp2f((float)l * f->S) * (float)f->H - 1.0f;
         P.resolution[l] = (uint32_t)ceilf(P.scale[l]) + 1u;
@@ -331,9 +355,6 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU 2             // two 8-wave workgroups per CU = 4 waves per SIMD, 62 KiB LDS each
 #endif
-#ifndef RV_PAIR_LOADS
-#define RV_PAIR_LOADS 1                // 8-byte loads for x-neighbour pairs that share an aligned row pair
-#endif
 #ifndef RV_PATCH_4X4
 #define RV_PATCH_4X4 1                 // each 16-lane column group covers a 4x4 pixel patch
 #endif
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict_
 // The march state of ngp_march_t split in two so that only what differs per ray occupies VGPRs:
 struct rv_ray { float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz; };
 struct rv_consts {                                     // wave-uniform (SGPRs), same formulas as ngp_march_t::setup
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
+    float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
     const uint8_t* grid;
     __device__ __forceinline__ int mip(int e) const { return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e)); }
 };
@@ -398,8 +419,10 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
     (void)frexpf((dt * m.Hf) * 0.5f, &e_dt);
     const int lp = m.mip(e_pos), ld = m.mip(e_dt);
     const int level = lp > ld ? lp : ld;
-    const float mip_bound = fminf((float)(1 << level), m.bound);
-    const float mip_rbound = 1.0f / mip_bound;
+    const float p2 = (float)(1 << level);
+    const float mip_bound = fminf(p2, m.bound);
+    // 1 / mip_bound without a division per probe: 2^-level is exact and 1 / bound is the same IEEE quotient, computed once
+    const float mip_rbound = (p2 <= m.bound) ? __builtin_ldexpf(1.0f, -level) : m.rbound;
     const int nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
     const int ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
     const int nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
@@ -434,7 +457,17 @@ __device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int 
 __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w, int lane,
                                               float px, float py, float pz, ngp_h4 shq,
                                               float& sigma, float& cr, float& cg, float& cb) {
+#ifdef RV_EXPERIMENT_NOENCODE      // timing-only build: no hash-grid encoding
+    ngp_h8 x;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = (_Float16)(px * (float)(j + 1) + py);
+#else
     const ngp_h8 x = rf_encode(P, lv, px, py, pz);
+#endif
+#ifdef RV_EXPERIMENT_NOMLP         // timing-only build: no MLP
+    sigma = 20.0f * fabsf((float)x[0] + (float)x[3]); cr = (float)x[1]; cg = (float)x[2]; cb = (float)shq[0];
+    return;
+#endif
     const ngp_f4 zero = {0.f, 0.f, 0.f, 0.f};
     ngp_h8 act[2];
     {
@@ -481,10 +514,17 @@ __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_
     ngp_f4 o = ngp_mfma(rv_frag(lds_w, 34, lane), act[0], zero);
     o = ngp_mfma(rv_frag(lds_w, 35, lane), act[1], o);
 
-    sigma = P.density_scale * ngp_expf(rf_h(h[0]));
-    cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[0]))));
-    cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[1]))));
-    cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[2]))));
+    // raw network outputs (lanes g == 0: density logit and the three colour logits of column s); the activations are
+    // applied once per round by the lane that owns the sample (rv_activate), not once per pass by all 64 lanes
+    sigma = h[0]; cr = o[0]; cg = o[1]; cb = o[2];
+}
+
+// trunc_exp forward (activation.py:9-10, fp32 of the half logit) times density_scale, and torch.sigmoid on the half logits
+__device__ __forceinline__ void rv_activate(const rf_params& P, float& sigma, float& cr, float& cg, float& cb) {
+    sigma = P.density_scale * ngp_expf(rf_h(sigma));
+    cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(cr))));
+    cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(cg))));
+    cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(cb))));
 }
 
 // queue index -> ray id.  With tile_w set (rays are a row-major image whose width and height are multiples of 8)
@@ -543,7 +583,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
 
     // wave-uniform march constants (ngp_march_t::setup's formulas), kept out of the per-ray state
     rv_consts K;
-    K.bound = P.bound; K.dt_gamma = F.dt_gamma;
+    K.bound = P.bound; K.rbound = 1.0f / P.bound; K.dt_gamma = F.dt_gamma;
     K.Hf = (float)F.H; K.Cf = (float)F.C; K.Hm1 = (float)(F.H - 1);
     K.rH = 1.0f / K.Hf;
     K.H3 = (float)(F.H * F.H * F.H);
@@ -634,6 +674,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
         // ---- composite (kernel_composite_rays arithmetic, raymarching.cu:865-896) ----
         bool done = ended;
         if (has) {
+            rv_activate(P, sig, sr, sg, sb);
             n_samples_local++;
             const float alpha = 1.0f - ngp_expf(-sig * dt);
             const float T = 1 - ws;

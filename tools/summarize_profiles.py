@@ -18,7 +18,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-ks = glob.glob(os.path.join(src, f"{tag}_kt", "*", "*kernel_stats.csv"))
+def newest(pattern):
+    """rocprofv3 names its files by PID and gpurun merges into an existing directory: keep the most recent run only"""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+ks = newest(os.path.join(src, f"{tag}_kt", "*", "*kernel_stats.csv"))
 assert ks, "no kernel-trace stats found"
 shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(ks[0]))}
@@ -26,7 +32,7 @@ kname = next(n for n in stats if "k_render_frame" in n)
 avg_ms = float(stats[kname]["AverageNs"]) / 1e6
 
 counters = {}
-for f in sorted(glob.glob(os.path.join(src, f"{tag}_pmc*", "*", "*counter_collection.csv"))):
+for f in sorted(sum((newest(os.path.join(d, "*", "*counter_collection.csv")) for d in glob.glob(os.path.join(src, f"{tag}_pmc*"))), [])):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         if "k_render_frame" in r["Kernel_Name"]:
