@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)     # ~1 s of GPU time; runs shorter than ~50 frames scatter by +-10 %
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--cpu-res", type=int, default=96, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -349,12 +349,17 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 // Tuning knobs, each A/B-measured on MI355X with tools/ab_variants.sh (800x800 S-ring frame, ms per frame):
 //   256 thr x 2/CU (2 waves/SIMD) 16.8 | 256 x 3 (3 waves/SIMD, 164 VGPR) 12.2 | + paired loads (136 VGPR) 10.5
 //   | 512 x 2 (4 waves/SIMD, 128 VGPR, 24 B/lane scratch) 9.2 | + 4x4 patches 9.1
+//   | packed-half ReLU, activations once per round, exact reciprocals 8.2 | RV_S = 4 samples per ray per round
+//   (1024 x 1, 156 KiB LDS) 6.85   (100 timed frames each; short runs scatter by +-10 %)
+#ifndef RV_S
+#define RV_S 4                         // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
+#endif
 #ifndef RV_BLOCK_THREADS
-#define RV_BLOCK_THREADS 512
+#define RV_BLOCK_THREADS (RV_S > 1 ? 1024 : 512)
 #endif
 #ifndef RV_BLOCKS_PER_CU
-#define RV_BLOCKS_PER_CU 2             // two 8-wave workgroups per CU = 4 waves per SIMD, 62 KiB LDS each
-#endif
+#define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
+#endif                                        // RV_S = 4 (80 KiB) only fit beside ONE copy of the weights per CU
 #ifndef RV_PATCH_4X4
 #define RV_PATCH_4X4 1                 // each 16-lane column group covers a 4x4 pixel patch
 #endif
@@ -702,6 +707,200 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
     if (lane == 0 && tot) atomicAdd(F.stats, tot);
 }
 
+// ---------------------------------------------------------------------------
+// k_render_frame_multi: the same frame kernel with RV_S samples per ray per round.
+//
+// The march is a lock-step loop: as long as one lane of the wave is still crossing empty space the other 63 wait, and in
+// steady state some lane always is.  Here a round's march loop lets every lane collect up to RV_S samples (lanes in
+// dense space fill up in RV_S iterations, lanes in empty space use the whole probe budget), so its cost is shared by up
+// to RV_S samples per lane instead of one.  Samples wait in an LDS slot array [lane][RV_S] = (x, y, z, dt) + d1; the field
+// is evaluated tile by tile, a tile being sample k of the 16 rays of one column group; the half-precision network outputs
+// overwrite the first 8 bytes of the slot; each lane then composites its samples in order.  A ray that saturates at
+// sample j < count has marched count-1-j samples too many: they are discarded (they were never composited, so images,
+// counts and statistics are identical to the one-sample kernel); the price is their field evaluation.
+// ---------------------------------------------------------------------------
+#if RV_S > 1
+static constexpr uint32_t RV_LDS_SMP = RV_WAVES * 64 * RV_S * 20;      // per sample: float4 (x, y, z, dt) + float d1
+
+__global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_multi(rf_params P, rf_frame F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
+    ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
+    _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
+    rf_lane_levels* lds_lv = reinterpret_cast<rf_lane_levels*>(rv_smem + RV_LDS_W + RV_LDS_SH);
+    float4* lds_smp = reinterpret_cast<float4*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV);
+    float* lds_d1 = reinterpret_cast<float*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_WAVES * 64 * RV_S * 16);
+    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_SMP) : nullptr;
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
+
+    for (int f = wave; f < RV_NFRAG; f += RV_WAVES) {
+        ngp_h8 a;
+        const _Float16* Wc = P.w_color;
+        const _Float16* Wch = Wc + MLP_W * 32;
+        if (f < 4) a = mlp_load_a_natural(P.w_sigma, 32, 32, f, 0, lane);
+        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
+        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
+        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
+        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
+        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
+        lds_w[f * 64 + lane] = a;
+    }
+    if (lds_coarse) {
+        const uint32_t nw = F.coarse_words * F.C;
+        for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
+    }
+    if (wave == 0 && s == 0) {
+        rf_lane_levels tmp;
+        rf_setup_levels(P, g, tmp);
+        lds_lv[g] = tmp;
+    }
+    __syncthreads();
+
+    _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;
+    const _Float16* wave_sh = lds_sh + wave * 64 * 16;
+    float4* my_smp = lds_smp + (wave * 64 + lane) * RV_S;               // this lane's sample slots
+    float* my_d1 = lds_d1 + (wave * 64 + lane) * RV_S;
+    float4* wave_smp = lds_smp + wave * 64 * RV_S;
+
+    rv_consts K;
+    K.bound = P.bound; K.rbound = 1.0f / P.bound; K.dt_gamma = F.dt_gamma;
+    K.Hf = (float)F.H; K.Cf = (float)F.C; K.Hm1 = (float)(F.H - 1);
+    K.rH = 1.0f / K.Hf;
+    K.H3 = (float)(F.H * F.H * F.H);
+    K.dt_min = (2.0f * 1.7320508075688772f) / (float)F.max_steps;
+    K.dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf;
+    K.grid = F.bitfield;
+
+    bool active = false;
+    uint32_t ray = 0, nsamp = 0;
+    rv_ray m;
+    float t = 0, last_t = 0, near = 0, far = 0;
+    float ws = 0, dacc = 0, cr = 0, cg = 0, cb = 0, tcomp = 0;
+    bool exhausted = false;
+    uint32_t n_samples_local = 0;
+
+    for (;;) {
+        if (!exhausted) {
+            const unsigned long long need = __ballot(!active);
+            if (need) {
+                const uint32_t cnt = (uint32_t)__popcll(need);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(F.queue, cnt);
+                base = __shfl(base, 0, 64);
+                if (!active) {
+                    const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                    if (idx < F.N) {
+                        ray = rv_ray_of(idx, F.tile_w);
+                        const float* o = F.rays_o + 3ull * ray;
+                        const float* d = F.rays_d + 3ull * ray;
+                        ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
+                        m.ox = o[0]; m.oy = o[1]; m.oz = o[2];
+                        m.dx = d[0]; m.dy = d[1]; m.dz = d[2];
+                        m.rdx = 1.0f / m.dx; m.rdy = 1.0f / m.dy; m.rdz = 1.0f / m.dz;
+                        t = near; last_t = near; tcomp = near;
+                        ws = 0; dacc = 0; cr = 0; cg = 0; cb = 0; nsamp = 0;
+                        float sh[16];
+                        sh_eval<4>(m.dx, m.dy, m.dz, P.shn, sh);
+                        #pragma unroll
+                        for (int j = 0; j < 16; j++) my_sh[j] = (_Float16)sh[j];
+                        active = true;
+                    }
+                }
+                if (base + cnt >= F.N) exhausted = true;
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+
+        // ---- march: up to RV_S samples per lane within one shared probe budget ----
+        int cnt = 0;
+        bool ended = false;
+        if (active) {
+            int probes = 0;
+            for (;;) {
+                if (!(t < far && nsamp < F.max_steps)) { ended = true; break; }
+                float x, y, z, dt;
+                if (rv_probe(m, K, lds_coarse, F.coarse_words, t, x, y, z, dt)) {
+                    t += dt;
+                    my_smp[cnt] = make_float4(x, y, z, dt);
+                    my_d1[cnt] = t - last_t;
+                    last_t = t;
+                    nsamp++;
+                    if (++cnt == RV_S) break;
+                }
+                if (++probes >= RF_PROBES_PER_ROUND) break;
+            }
+        }
+
+        // lanes hand samples to other lanes of the SAME wave through LDS: the LDS queue of a wave is in order, so only the
+        // compiler has to be kept from reordering the accesses
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- field evaluation: for each group of 16 rays, tile k = their k-th samples ----
+        #pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int src = 16 * p + s;
+            const int ccol = __shfl(cnt, src, 64);
+            if (__ballot(ccol > 0) == 0ull) continue;
+            const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
+            const rf_lane_levels lv = lds_lv[g];
+            #pragma unroll 1
+            for (int k = 0; k < RV_S; k++) {
+                if (__ballot(ccol > k) == 0ull) break;   // counts only shrink with k
+                float4 q = wave_smp[src * RV_S + k];
+                if (!(ccol > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);   // column without a k-th sample: harmless dummy
+                float a, b, c, d;
+                rv_field_tile(P, lv, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
+                if (g == 0 && ccol > k) {                // the half-precision network outputs replace (x, y) of the slot
+                    ngp_h4 r;
+                    r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
+                    *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k]) = r;
+                }
+            }
+        }
+
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- composite this lane's samples in order (kernel_composite_rays arithmetic, raymarching.cu:865-896) ----
+        bool done = false;
+        for (int k = 0; k < cnt; k++) {
+            const ngp_h4 r = *reinterpret_cast<const ngp_h4*>(&my_smp[k]);
+            const float dt = my_smp[k].w, d1 = my_d1[k];
+            float sig = (float)r[0], sr = (float)r[1], sg = (float)r[2], sb = (float)r[3];
+            rv_activate(P, sig, sr, sg, sb);
+            n_samples_local++;
+            const float alpha = 1.0f - ngp_expf(-sig * dt);
+            const float T = 1 - ws;
+            const float w = alpha * T;
+            ws += w;
+            tcomp += d1;
+            dacc += w * tcomp;
+            cr += w * sr; cg += w * sg; cb += w * sb;
+            if ((double)T < 1e-4) { done = true; break; }    // samples marched beyond this one are discarded
+        }
+        const bool capped = !done && ended && nsamp >= F.max_steps && t < far;
+        if (ended) done = true;
+        if (done) {
+            F.image[3ull * ray] = cr + (1 - ws) * F.bg[0];
+            F.image[3ull * ray + 1] = cg + (1 - ws) * F.bg[1];
+            F.image[3ull * ray + 2] = cb + (1 - ws) * F.bg[2];
+            F.depth[ray] = fmaxf(dacc - near, 0.0f) / (far - near);
+            F.weights_sum[ray] = ws;
+            if (capped) atomicAdd(F.stats + 1, 1u);
+            if (nsamp > 0) atomicAdd(F.stats + 2, 1u);
+            active = false;
+        }
+    }
+    uint32_t tot = n_samples_local;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    if (lane == 0 && tot) atomicAdd(F.stats, tot);
+}
+#endif  // RV_S > 1
+
 static inline bool rv_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
 extern "C" size_t ngp_render_frame_workspace(uint32_t N) {
@@ -741,6 +940,12 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     F.coarse = nullptr; F.coarse_words = 0;
     static_assert(sizeof(rf_lane_levels) * 4 == RV_LDS_LV, "LDS carve of the level table");
     size_t lds = RV_LDS_W + RV_LDS_SH + RV_LDS_LV;
+#if RV_S > 1
+    lds += RV_LDS_SMP;
+    const void* kernel = reinterpret_cast<const void*>(k_render_frame_multi);
+#else
+    const void* kernel = reinterpret_cast<const void*>(k_render_frame);
+#endif
     const uint64_t blocks_per_level = (uint64_t)Hgrid * Hgrid * Hgrid / 64;
     const uint64_t coarse_bytes = (uint64_t)C * blocks_per_level / 8;
     if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && coarse_bytes <= 48 * 1024 &&
@@ -752,9 +957,10 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
         F.coarse_words = (uint32_t)(blocks_per_level / 32);
         lds += coarse_bytes;
     }
+    NGP_REQUIRE(lds <= 160 * 1024, "render_frame: LDS carve exceeds 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_frame), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return ngp_fail(NGP_ELAUNCH, "render_frame: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
@@ -762,7 +968,11 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     uint32_t blocks = 256 * RV_BLOCKS_PER_CU;
     const uint32_t need = ngp_div_up(N, RV_BLOCK);
     if (blocks > need) blocks = need;
+#if RV_S > 1
+    hipLaunchKernelGGL(k_render_frame_multi, dim3(blocks), dim3(RV_BLOCK), lds, s, P, F);
+#else
     hipLaunchKernelGGL(k_render_frame, dim3(blocks), dim3(RV_BLOCK), lds, s, P, F);
+#endif
     NGP_CHECK_LAUNCH("render_frame");
     return NGP_OK;
 }
