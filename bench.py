@@ -30,6 +30,59 @@ MLP_FLOPS_PER_SAMPLE = 2 * (64 * (32 + 64 + 16) + 64 * (32 + 128 + 16))   # FFML
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
+def bench_train(args, rank, world, dev, W, teacher):
+    """Secondary metric: training throughput of the op-by-op path with autograd (main_nerf.py's recipe, ngp/train.py).
+    Each rank draws its own 4096-ray batches from its own views; gradients are averaged with one all-reduce per step."""
+    import torch.distributed as dist
+    from ngp import sharding
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    from ngp.train import NGPTrainer
+    res, n_rays = 200, 4096
+    intr = W.intrinsics(res, res)
+    pool = []
+    for view in sharding.pose_indices(rank, world, 8):
+        o, d = W.get_rays(W.orbit_pose(view, 8 * world), intr, res, res)
+        to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+        pool.append((to, td, teacher.render_fused(to, td, bg_color=1, image_width=res)["image"]))
+    torch.manual_seed(0)                                                    # identical initial replicas
+    student = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
+    tr = NGPTrainer(student, lr=1e-2, iters=30000, fp16=True)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+
+    def step(k):
+        to, td, tc = pool[k % len(pool)]
+        idx = torch.randint(0, res * res, (n_rays,), device=dev, generator=gen)
+        return tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=1024)
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        loss = step(args.warmup + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n = min(16, student.local_step) or 1
+    points = float(student.step_counter[:n, 0].float().mean().item()) if student.local_step else float(student.mean_count)
+    rays_all, t_max = sharding.reduce_throughput(n_rays * args.steps, elapsed, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training rays/sec (4096-ray steps, FFMLP field under autocast, Adam, grid refresh every 16 steps)",
+            "value": rays_all / t_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "S-ring training (teacher-rendered 200x200 views), op-by-op HIP path with autograd",
+                       "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": float(loss)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,6 +92,8 @@ def main():
     ap.add_argument("--cpu-res", type=int, default=96, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--path", default="fused", choices=["fused", "per_op"], help="per_op = the reference-shaped op-by-op loop")
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render = the headline metric; train = secondary: training steps (configs 3 / 5), 4096 rays per step per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,6 +116,9 @@ def main():
     field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(model)
     ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
     ren.load_density_grid(grid)
+
+    if args.mode == "train":
+        return bench_train(args, rank, world, dev, W, ren)
 
     H = Wd = args.res
     intr = W.intrinsics(H, Wd)
