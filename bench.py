@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)     # ~1 s of GPU time; runs shorter than ~50 frames scatter by +-10 %
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--cpu-res", type=int, default=96, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
+    ap.add_argument("--cpu-res", type=int, default=144, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--path", default="fused", choices=["fused", "per_op"], help="per_op = the reference-shaped op-by-op loop")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
@@ -251,10 +251,10 @@ def main():
         result["cpu_baseline"] = {
             "value": ref["samples"] / cpu_s,
             "unit": "ray-samples/s",
-            "cores": os.cpu_count(),
+            "cores": len(os.sched_getaffinity(0)),
             "kind": "port",
             "sample": f"one {r}x{r} frame of the same scene and model through oracle run_cuda "
-                      f"({ref['samples']} ray-samples, {cpu_s:.1f} s, OpenMP over all cores)",
+                      f"({ref['samples']} ray-samples, {cpu_s:.1f} s, OpenMP over the cores this process may use)",
         }
     print(json.dumps(result))
     if world > 1:
