@@ -212,7 +212,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "k_render_frame" if args.path == "fused" else "per-op loop (many kernels)",
+            "kernel": "k_render_frame_multi" if args.path == "fused" else "per-op loop (many kernels)",
             "avg_launch_ms": 1e3 * avg_kernel_s,
             "algorithmic_bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
             "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,

@@ -26,14 +26,6 @@
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 
-// knobs of the encoder (used by rf_encode below, so they are defined first)
-#ifndef RV_PAIR_LOADS
-#define RV_PAIR_LOADS 1                // 8-byte loads for x-neighbour pairs that share an aligned row pair
-#endif
-#ifndef RF_LEVEL_BATCH
-#define RF_LEVEL_BATCH 4               // levels gathered before blending (1, 2 or 4)
-#endif
-
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
 #ifndef RF_PROBES_PER_ROUND
@@ -52,22 +44,29 @@ struct rf_params {
     sh_norm shn;
 };
 
-// per-lane constants of the 4 levels a lane group gathers
+// Level -> lane mapping.  Lane group g = lane >> 4 gathers, in iteration i = 0..3, level 4i + g, and holds its two
+// features at slots 2i, 2i+1 of the first layer's B fragment (the first layer's A fragments are loaded in that same k
+// order, rf_load_a_sigma_in).  Interleaving the levels over the lane groups makes an ITERATION nearly uniform across the
+// wave: in the reference's 16-level grid, iteration 0 is levels 0..3 (all dense), iterations 2 and 3 are levels 8..15
+// (all hashed) and only iteration 1 (levels 4..7) mixes both kinds, so three of four iterations run straight-line code
+// for one kind of level instead of executing both sides of a per-lane branch.
 struct rf_lane_levels {
     float scale[4];
-    uint32_t base[4], size[4], s1[4], s2[4];   // row offset, rows, strides (dense) ; s1 == 0 marks a hashed level
-    uint32_t mask[4];                          // size-1 when size is a power of two, else 0
+    uint32_t base4[4];                         // byte offset of the level's first row in the table
+    uint32_t size[4];                          // rows
+    uint32_t s1b[4], s2b[4];                   // dense level: y and z strides in BYTES; s1b == 0 marks a hashed level
+    uint32_t mask4[4];                         // hashed level with 2^k rows: (rows - 1) * 4, else 0
 };
 
 __device__ __forceinline__ void rf_setup_levels(const rf_params& P, int g, rf_lane_levels& lv) {
     #pragma unroll
     for (int i = 0; i < 4; i++) {
         // select by lane group from the scalar (kernarg) arrays
-        float sc = P.scale[i]; uint32_t rs = P.resolution[i];
-        if (g == 1) { sc = P.scale[4 + i]; rs = P.resolution[4 + i]; }
-        if (g == 2) { sc = P.scale[8 + i]; rs = P.resolution[8 + i]; }
-        if (g == 3) { sc = P.scale[12 + i]; rs = P.resolution[12 + i]; }
-        const int level = 4 * g + i;
+        float sc = P.scale[4 * i]; uint32_t rs = P.resolution[4 * i];
+        if (g == 1) { sc = P.scale[4 * i + 1]; rs = P.resolution[4 * i + 1]; }
+        if (g == 2) { sc = P.scale[4 * i + 2]; rs = P.resolution[4 * i + 2]; }
+        if (g == 3) { sc = P.scale[4 * i + 3]; rs = P.resolution[4 * i + 3]; }
+        const int level = 4 * i + g;
         const uint32_t o0 = (uint32_t)P.offsets[level], o1 = (uint32_t)P.offsets[level + 1];
         const uint32_t size = o1 - o0;
         // reference get_grid_index (gridencoder.cu:54-72): the stride stops growing once it exceeds hashmap_size
@@ -82,84 +81,120 @@ __device__ __forceinline__ void rf_setup_levels(const rf_params& P, int g, rf_la
             } else dense = false;
         }
         if (stride > size) dense = false;
-        lv.scale[i] = sc; lv.base[i] = o0; lv.size[i] = size;
-        lv.s1[i] = dense ? s1 : 0u; lv.s2[i] = dense ? s2 : 0u;
-        lv.mask[i] = ((size & (size - 1)) == 0) ? (size - 1) : 0u;
+        if (rs + 1 > 1024u) dense = false;     // keeps the 24-bit multiplies of the dense path exact; such a level is hashed anyway
+        lv.scale[i] = sc; lv.base4[i] = o0 * 4u; lv.size[i] = size;
+        lv.s1b[i] = dense ? s1 * 4u : 0u; lv.s2b[i] = dense ? s2 * 4u : 0u;
+        lv.mask4[i] = (!dense && (size & (size - 1)) == 0) ? (size - 1) * 4u : 0u;
     }
+}
+
+// Which kind of code each iteration needs, decided once per kernel by the whole wave (bit i = iteration i).
+struct rf_iter_class { uint32_t dense, hashed, select; };
+
+__device__ __forceinline__ rf_iter_class rf_classify(const rf_lane_levels& lv) {   // call with all 64 lanes active
+    rf_iter_class c = {0u, 0u, 0u};
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long bd = __ballot(lv.s1b[i] != 0u), bh = __ballot(lv.mask4[i] != 0u);
+        if (bd == ~0ull) c.dense |= 1u << i;                       // every lane: dense level
+        else if (bh == ~0ull) c.hashed |= 1u << i;                 // every lane: hashed level with 2^k rows
+        else if ((bd | bh) == ~0ull) c.select |= 1u << i;          // a mix of those two
+    }                                                              // otherwise (a hashed level whose size is not 2^k): generic
+    return c;
 }
 
 __device__ __forceinline__ float rf_h(float v) { return (float)(_Float16)v; }   // round to half, back to float
 
-// Hash-grid encoding of one sample for the 4 levels of this lane's group -> 8 half features (k = 8g + 2i + ch).
-// Arithmetic identical, operation for operation, to k_grid_forward<_Float16,3,2> (gridencoder.hip).
-__device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, float wx, float wy, float wz) {
+struct rf_row2 { uint32_t lo, hi; };                                          // two consecutive rows
+__device__ __forceinline__ uint32_t rf_row(const rf_params& P, uint32_t byte_off) {
+    asm("" : "+v"(byte_off));      // keep the 32-bit offset a VGPR value of its own: the load is then SGPR base + VGPR offset
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(P.table) + byte_off);
+}
+__device__ __forceinline__ rf_row2 rf_rows(const rf_params& P, uint32_t byte_off) {   // one 8-byte load, 4-byte aligned
+    asm("" : "+v"(byte_off));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef u2 u2_a4 __attribute__((aligned(4)));
+    const u2 v = *reinterpret_cast<const u2_a4*>(reinterpret_cast<const char*>(P.table) + byte_off);
+    return rf_row2{v.x, v.y};
+}
+
+// Hash-grid encoding of one sample for the 4 levels of this lane's group -> 8 half features (slot 2i + ch = level 4i + g).
+// Arithmetic identical, operation for operation, to k_grid_forward<_Float16,3,2> (gridencoder.hip); only the address
+// computation is arranged differently (byte offsets, strides folded into multiply-adds, the hash computed pre-shifted:
+// (y * p) << 2 == y * (p << 2) mod 2^32, and the power-of-two modulo taken on the operands: (a ^ b) & m == (a & m) ^ (b & m)).
+__device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
+                                            float wx, float wy, float wz) {
     // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound).  When 2*bound is a power of two (every cascade-aligned
     // bound) the quotient equals the product with the exact reciprocal, bit for bit, and skips three IEEE divisions.
     const float b2 = 2 * P.bound;
     float x0, x1, x2;
     if (P.inv_b2 != 0.0f) { x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2; }
     else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
+    // a sample outside [0,1]^3 encodes to zeros (gridencoder.cu:118-131); it gathers at the origin so that no load needs a guard
     const bool oob = (x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1);
-    // RF_LEVEL_BATCH levels are gathered (all their loads in flight) before they are blended.  4 = maximum memory-level
-    // parallelism, 2 = 16 fewer live VGPRs: the kernel is issue-bound, not latency-bound, at 4 waves per SIMD.
-    ngp_h8 out;
-    #pragma unroll
-    for (int b0 = 0; b0 < 4; b0 += RF_LEVEL_BATCH) {
+    if (oob) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; }
+    constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;              // fast_hash primes (gridencoder.cu:35-51)
     uint32_t raw[4][8];
     float fx[4], fy[4], fz[4];
     #pragma unroll
-    for (int i = b0; i < b0 + RF_LEVEL_BATCH; i++) {
+    for (int i = 0; i < 4; i++) {
         const float sc = lv.scale[i];
-        float px = x0 * sc + 0.5f, py = x1 * sc + 0.5f, pz = x2 * sc + 0.5f;
-        const uint32_t gx = (uint32_t)floorf(px), gy = (uint32_t)floorf(py), gz = (uint32_t)floorf(pz);
-        fx[i] = px - (float)gx; fy[i] = py - (float)gy; fz[i] = pz - (float)gz;
-        uint32_t idx[8];
-        if (lv.s1[i] != 0u) {                          // dense level: x + y*s1 + z*s2 (always < size)
-            const uint32_t ay = gy * lv.s1[i], az = gz * lv.s2[i];
-            #pragma unroll
-            for (int c = 0; c < 8; c++)
-                idx[c] = (gx + (c & 1)) + (ay + ((c & 2) ? lv.s1[i] : 0u)) + (az + ((c & 4) ? lv.s2[i] : 0u));
-        } else {                                       // hashed level: x ^ y*p1 ^ z*p2 (fast_hash, gridencoder.cu:35-51)
-            const uint32_t hy = gy * 2654435761u, hz = gz * 805459861u;
-            #pragma unroll
-            for (int c = 0; c < 8; c++)
-                idx[c] = (gx + (c & 1)) ^ (hy + ((c & 2) ? 2654435761u : 0u)) ^ (hz + ((c & 4) ? 805459861u : 0u));
-            if (lv.mask[i] != 0u) {                    // 2^k rows (the usual 2^19): modulo is a mask
-                #pragma unroll
-                for (int c = 0; c < 8; c++) idx[c] &= lv.mask[i];
+        const float px = x0 * sc + 0.5f, py = x1 * sc + 0.5f, pz = x2 * sc + 0.5f;
+        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+        const uint32_t gx = (uint32_t)flx, gy = (uint32_t)fly, gz = (uint32_t)flz;
+        fx[i] = px - flx; fy[i] = py - fly; fz[i] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
+        const uint32_t bit = 1u << i;
+        if (cls.dense & bit) {
+            // x + y*s1 + z*s2 (always < size); the x-neighbour is the next row: one 8-byte load per (y, z)
+            const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + lv.base4[i]));
+            const uint32_t o01 = o00 + lv.s1b[i], o10 = o00 + lv.s2b[i], o11 = o01 + lv.s2b[i];
+            const rf_row2 r0 = rf_rows(P, o00), r1 = rf_rows(P, o01), r2 = rf_rows(P, o10), r3 = rf_rows(P, o11);
+            raw[i][0] = r0.lo; raw[i][1] = r0.hi; raw[i][2] = r1.lo; raw[i][3] = r1.hi;
+            raw[i][4] = r2.lo; raw[i][5] = r2.hi; raw[i][6] = r3.lo; raw[i][7] = r3.hi;
+        } else {
+            uint32_t off[8];                                           // byte offsets of the 8 corners
+            if (cls.hashed & bit) {
+                const uint32_t m = lv.mask4[i], b = lv.base4[i];
+                const uint32_t hy = gy * (P1 << 2), hz = gz * (P2 << 2);
+                const uint32_t hy1 = hy + (P1 << 2), hz1 = hz + (P2 << 2);
+                const uint32_t a0 = (gx << 2) & m, a1 = ((gx << 2) + 4u) & m;
+                const uint32_t yz0 = (hy ^ hz) & m, yz1 = (hy1 ^ hz) & m, yz2 = (hy ^ hz1) & m, yz3 = (hy1 ^ hz1) & m;
+                off[0] = (a0 ^ yz0) + b; off[1] = (a1 ^ yz0) + b; off[2] = (a0 ^ yz1) + b; off[3] = (a1 ^ yz1) + b;
+                off[4] = (a0 ^ yz2) + b; off[5] = (a1 ^ yz2) + b; off[6] = (a0 ^ yz3) + b; off[7] = (a1 ^ yz3) + b;
+            } else if (cls.select & bit) {
+                // both kinds in one wave: compute both offsets, select per lane, no branch
+                const bool dense = lv.s1b[i] != 0u;
+                const uint32_t m = lv.mask4[i], b = lv.base4[i];
+                const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + b));
+                const uint32_t o01 = o00 + lv.s1b[i], o10 = o00 + lv.s2b[i], o11 = o01 + lv.s2b[i];
+                const uint32_t hy = gy * (P1 << 2), hz = gz * (P2 << 2);
+                const uint32_t hy1 = hy + (P1 << 2), hz1 = hz + (P2 << 2);
+                const uint32_t a0 = (gx << 2) & m, a1 = ((gx << 2) + 4u) & m;
+                const uint32_t yz0 = (hy ^ hz) & m, yz1 = (hy1 ^ hz) & m, yz2 = (hy ^ hz1) & m, yz3 = (hy1 ^ hz1) & m;
+                off[0] = dense ? o00 : (a0 ^ yz0) + b; off[1] = dense ? o00 + 4u : (a1 ^ yz0) + b;
+                off[2] = dense ? o01 : (a0 ^ yz1) + b; off[3] = dense ? o01 + 4u : (a1 ^ yz1) + b;
+                off[4] = dense ? o10 : (a0 ^ yz2) + b; off[5] = dense ? o10 + 4u : (a1 ^ yz2) + b;
+                off[6] = dense ? o11 : (a0 ^ yz3) + b; off[7] = dense ? o11 + 4u : (a1 ^ yz3) + b;
             } else {
+                // generic: any mix, including a hashed level whose row count is not a power of two (index % size);
+                // branch-free like the rest, so that the choice of class stays the only (wave-uniform) control flow
+                const bool dense = lv.s1b[i] != 0u;
+                const uint32_t s1 = lv.s1b[i] >> 2, s2 = lv.s2b[i] >> 2;
+                const uint32_t hy = gy * P1, hz = gz * P2;
                 #pragma unroll
-                for (int c = 0; c < 8; c++) idx[c] %= lv.size[i];
+                for (int c = 0; c < 8; c++) {
+                    const uint32_t id = (gx + (c & 1)) + (gy * s1 + ((c & 2) ? s1 : 0u)) + (gz * s2 + ((c & 4) ? s2 : 0u));
+                    const uint32_t ih = ((gx + (c & 1)) ^ (hy + ((c & 2) ? P1 : 0u)) ^ (hz + ((c & 4) ? P2 : 0u))) % lv.size[i];
+                    off[c] = (dense ? id : ih) * 4u + lv.base4[i];
+                }
             }
+            #pragma unroll
+            for (int c = 0; c < 8; c++) raw[i][c] = rf_row(P, off[c]);
         }
-        const uint32_t* tab = P.table + lv.base[i];
-#if RV_PAIR_LOADS
-        // The two x-neighbours of a (y,z) pair often sit in one aligned 8-byte pair of rows (dense level with an even
-        // row, hashed level with an even x: x ^ K and (x+1) ^ K then differ in bit 0 only): one 8-byte load instead of
-        // two 4-byte loads, i.e. fewer L1 requests for the same bytes.
-        #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t i0 = idx[2 * q], i1 = idx[2 * q + 1];
-            if (oob) { raw[i][2 * q] = 0u; raw[i][2 * q + 1] = 0u; }
-#ifdef RV_EXPERIMENT_NOLOADS       // timing-only build: what the kernel costs without its table gathers
-            else if (true) { raw[i][2 * q] = i0 * 0x9E3779B1u; raw[i][2 * q + 1] = i1 * 0x9E3779B1u; }
-#endif
-            else if ((i0 ^ i1) == 1u) {
-                const uint2 v = *reinterpret_cast<const uint2*>(tab + (i0 & ~1u));
-                raw[i][2 * q] = (i0 & 1u) ? v.y : v.x;
-                raw[i][2 * q + 1] = (i0 & 1u) ? v.x : v.y;
-            } else {
-                raw[i][2 * q] = tab[i0];
-                raw[i][2 * q + 1] = tab[i1];
-            }
-        }
-#else
-        #pragma unroll
-        for (int c = 0; c < 8; c++) raw[i][c] = oob ? 0u : tab[idx[c]];
-#endif
     }
+    ngp_h8 out;
     #pragma unroll
-    for (int i = b0; i < b0 + RF_LEVEL_BATCH; i++) {
+    for (int i = 0; i < 4; i++) {
         float r0 = 0.0f, r1 = 0.0f;
         #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -174,13 +209,23 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
         out[2 * i] = (_Float16)r0;
         out[2 * i + 1] = (_Float16)r1;
     }
-    if (b0 + RF_LEVEL_BATCH < 4) __builtin_amdgcn_sched_barrier(0);    // keep the next batch's loads below this point
-    }
     if (oob) {
         #pragma unroll
         for (int j = 0; j < 8; j++) out[j] = (_Float16)0.0f;
     }
     return out;
+}
+
+// density-net first layer, A fragments in rf_encode's k order: slots 2i, 2i+1 of lane group g = features of level 4i + g
+__device__ __forceinline__ ngp_h8 rf_load_a_sigma_in(const _Float16* __restrict__ W, int t, int lane) {
+    const int row = 16 * t + (lane & 15), g = lane >> 4;
+    ngp_h8 a;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[2 * i] = W[row * 32 + 2 * (4 * i + g)];
+        a[2 * i + 1] = W[row * 32 + 2 * (4 * i + g) + 1];
+    }
+    return a;
 }
 
 // colour-net first layer, A fragments in the k order {h[4g..4g+3], SH[4g..4g+3]} (see the header comment)
@@ -204,6 +249,8 @@ struct rf_weights {
     __device__ __forceinline__ void load(const rf_params& P, int lane) {
         sig.load(P.w_sigma, 32, lane);
         #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) sig.w_in[t][0] = rf_load_a_sigma_in(P.w_sigma, t, lane);
+        #pragma unroll
         for (int t = 0; t < MLP_MT; t++) c_in[t] = rf_load_a_color_in(P.w_color, t, lane);
         const _Float16* Wh = P.w_color + MLP_W * 32;
         #pragma unroll
@@ -219,11 +266,11 @@ struct rf_weights {
 
 // One 16-column tile: (world position, direction) of column s's sample, held redundantly by its 4 lanes.
 // Returns, valid in lanes g == 0: sigma (already times density_scale) and rgb.
-__device__ __forceinline__ void rf_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_weights& W, int g,
+__device__ __forceinline__ void rf_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls, const rf_weights& W, int g,
                                               float px, float py, float pz, float dx, float dy, float dz,
                                               float& sigma, float& cr, float& cg, float& cb) {
     ngp_h8 x[1];
-    x[0] = rf_encode(P, lv, px, py, pz);
+    x[0] = rf_encode(P, lv, cls, px, py, pz);
     const ngp_f4 h = mlp_forward_tile<1, 1>(W.sig, x, [](int, const ngp_h8 (&)[2]) {});
 
     float sh[16];
@@ -277,6 +324,7 @@ __global__ __launch_bounds__(RF_BLOCK) void k_field_forward(rf_params P, const f
     const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
     rf_lane_levels lv;
     rf_setup_levels(P, g, lv);
+    const rf_iter_class cls = rf_classify(lv);
     rf_weights W;
     W.load(P, lane);
     const uint32_t ntiles = (M + 15) >> 4;
@@ -287,7 +335,7 @@ __global__ __launch_bounds__(RF_BLOCK) void k_field_forward(rf_params P, const f
         const float px = xyzs[3 * mm], py = xyzs[3 * mm + 1], pz = xyzs[3 * mm + 2];
         const float dx = dirs[3 * mm], dy = dirs[3 * mm + 1], dz = dirs[3 * mm + 2];
         float sigma, cr, cg, cb;
-        rf_field_tile(P, lv, W, g, px, py, pz, dx, dy, dz, sigma, cr, cg, cb);
+        rf_field_tile(P, lv, cls, W, g, px, py, pz, dx, dy, dz, sigma, cr, cg, cb);
         if (g == 0 && valid) {
             sigmas[m] = sigma;
             rgbs[3ull * m] = cr; rgbs[3ull * m + 1] = cg; rgbs[3ull * m + 2] = cb;
@@ -459,7 +507,8 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
 __device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int f, int lane) { return lds_w[f * 64 + lane]; }
 
 // rf_field_tile with the weights streamed from LDS and the SH coefficients of the column's ray read from LDS
-__device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w, int lane,
+__device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
+                                              const ngp_h8* __restrict__ lds_w, int lane,
                                               float px, float py, float pz, ngp_h4 shq,
                                               float& sigma, float& cr, float& cg, float& cb) {
 #ifdef RV_EXPERIMENT_NOENCODE      // timing-only build: no hash-grid encoding
@@ -467,7 +516,7 @@ __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_
     #pragma unroll
     for (int j = 0; j < 8; j++) x[j] = (_Float16)(px * (float)(j + 1) + py);
 #else
-    const ngp_h8 x = rf_encode(P, lv, px, py, pz);
+    const ngp_h8 x = rf_encode(P, lv, cls, px, py, pz);
 #endif
 #ifdef RV_EXPERIMENT_NOMLP         // timing-only build: no MLP
     sigma = 20.0f * fabsf((float)x[0] + (float)x[3]); cr = (float)x[1]; cg = (float)x[2]; cb = (float)shq[0];
@@ -549,6 +598,7 @@ __device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w) {
 #endif
 }
 
+#if RV_S == 1
 __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf_params P, rf_frame F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
@@ -562,7 +612,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
         ngp_h8 a;
         const _Float16* Wc = P.w_color;
         const _Float16* Wch = Wc + MLP_W * 32;
-        if (f < 4) a = mlp_load_a_natural(P.w_sigma, 32, 32, f, 0, lane);
+        if (f < 4) a = rf_load_a_sigma_in(P.w_sigma, f, lane);
         else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
         else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
         else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
@@ -582,6 +632,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
         lds_lv[g] = tmp;
     }
     __syncthreads();
+    const rf_iter_class cls = rf_classify(lds_lv[g]);
 
     _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;                // this lane's ray
     const _Float16* wave_sh = lds_sh + wave * 64 * 16;
@@ -671,7 +722,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             float a, b, c, d;
             const rf_lane_levels lv = lds_lv[g];
-            rv_field_tile(P, lv, lds_w, lane, qx, qy, qz, shq, a, b, c, d);
+            rv_field_tile(P, lv, cls, lds_w, lane, qx, qy, qz, shq, a, b, c, d);
             const float ra = __shfl(a, s, 64), rb = __shfl(b, s, 64), rc = __shfl(c, s, 64), rd = __shfl(d, s, 64);
             if (g == p) { sig = ra; sr = rb; sg = rc; sb = rd; }
         }
@@ -707,6 +758,8 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
     if (lane == 0 && tot) atomicAdd(F.stats, tot);
 }
 
+#endif  // RV_S == 1
+
 // ---------------------------------------------------------------------------
 // k_render_frame_multi: the same frame kernel with RV_S samples per ray per round.
 //
@@ -722,39 +775,16 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
 #if RV_S > 1
 static constexpr uint32_t RV_LDS_SMP = RV_WAVES * 64 * RV_S * 20;      // per sample: float4 (x, y, z, dt) + float d1
 
-__global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_multi(rf_params P, rf_frame F) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
-    ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
-    _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
-    rf_lane_levels* lds_lv = reinterpret_cast<rf_lane_levels*>(rv_smem + RV_LDS_W + RV_LDS_SH);
-    float4* lds_smp = reinterpret_cast<float4*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV);
-    float* lds_d1 = reinterpret_cast<float*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_WAVES * 64 * RV_S * 16);
-    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_SMP) : nullptr;
-
+// The persistent loop of k_render_frame_multi.  FIXED selects compile-time iteration classes for the reference's grid
+// (iteration 0 dense, 1 mixed, 2 and 3 hashed: 16 levels from 16^3 at 2^19 rows per level): with the classes constant the
+// encoder is straight-line code and all 32 gathers of a tile are in flight together; with run-time classes the compiler
+// chains the alternatives and waits for one iteration's loads before issuing the next.
+template <bool FIXED>
+__device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame& F, const rf_iter_class cls_rt,
+                                              const ngp_h8* __restrict__ lds_w, _Float16* lds_sh, const rf_lane_levels* lds_lv,
+                                              float4* lds_smp, float* lds_d1, const uint32_t* lds_coarse) {
+    const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
-
-    for (int f = wave; f < RV_NFRAG; f += RV_WAVES) {
-        ngp_h8 a;
-        const _Float16* Wc = P.w_color;
-        const _Float16* Wch = Wc + MLP_W * 32;
-        if (f < 4) a = mlp_load_a_natural(P.w_sigma, 32, 32, f, 0, lane);
-        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
-        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
-        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
-        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
-        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
-        lds_w[f * 64 + lane] = a;
-    }
-    if (lds_coarse) {
-        const uint32_t nw = F.coarse_words * F.C;
-        for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
-    }
-    if (wave == 0 && s == 0) {
-        rf_lane_levels tmp;
-        rf_setup_levels(P, g, tmp);
-        lds_lv[g] = tmp;
-    }
-    __syncthreads();
 
     _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;
     const _Float16* wave_sh = lds_sh + wave * 64 * 16;
@@ -851,7 +881,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
                 float4 q = wave_smp[src * RV_S + k];
                 if (!(ccol > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);   // column without a k-th sample: harmless dummy
                 float a, b, c, d;
-                rv_field_tile(P, lv, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
+                rv_field_tile(P, lv, cls, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
                 if (g == 0 && ccol > k) {                // the half-precision network outputs replace (x, y) of the slot
                     ngp_h4 r;
                     r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
@@ -898,6 +928,46 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(F.stats, tot);
+}
+
+__global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_multi(rf_params P, rf_frame F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
+    ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
+    _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
+    rf_lane_levels* lds_lv = reinterpret_cast<rf_lane_levels*>(rv_smem + RV_LDS_W + RV_LDS_SH);
+    float4* lds_smp = reinterpret_cast<float4*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV);
+    float* lds_d1 = reinterpret_cast<float*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_WAVES * 64 * RV_S * 16);
+    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_SMP) : nullptr;
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
+
+    for (int f = wave; f < RV_NFRAG; f += RV_WAVES) {
+        ngp_h8 a;
+        const _Float16* Wc = P.w_color;
+        const _Float16* Wch = Wc + MLP_W * 32;
+        if (f < 4) a = rf_load_a_sigma_in(P.w_sigma, f, lane);
+        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
+        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
+        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
+        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
+        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
+        lds_w[f * 64 + lane] = a;
+    }
+    if (lds_coarse) {
+        const uint32_t nw = F.coarse_words * F.C;
+        for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
+    }
+    if (wave == 0 && s == 0) {
+        rf_lane_levels tmp;
+        rf_setup_levels(P, g, tmp);
+        lds_lv[g] = tmp;
+    }
+    __syncthreads();
+    const rf_iter_class cls = rf_classify(lds_lv[g]);
+    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u)
+        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
+    else
+        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
 }
 #endif  // RV_S > 1
 
