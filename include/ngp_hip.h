@@ -215,12 +215,17 @@ int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const fl
  * image [N,3], depth [N], weights_sum [N] f32 are fully written (no pre-zeroing needed);
  * image already includes the background mix image + (1-ws)*bg_color and depth the (depth-near)/(far-near) map.
  * stats [4] u32 device (zeroed by the call): [0] ray-samples evaluated, [1] rays that consumed > max_steps samples
- * (schedule-dependent in the reference), [2] rays with at least one sample, [3] reserved.
+ * (schedule-dependent in the reference), [2] rays with at least one sample, [3] 16-column matrix-core tiles evaluated (ray-samples / (16 * tiles) is the
+ * packing efficiency; unlike [0..2] it depends on the traversal order).
  * image_width: when rays_o/rays_d are a row-major image (width and height multiples of 8) pass its width and the
  * kernel walks the rays in 8x8 pixel tiles for cache locality; 0 = rays in no particular order.  Results do not
  * depend on it.
  * workspace: ngp_render_frame_workspace(N) bytes. */
 size_t ngp_render_frame_workspace(uint32_t N);
+/* Validation switch, process-wide, default 1: ngp_render_frame jumps through empty 4^3 / 16^3 blocks of the occupancy
+ * grid when that provably visits the reference's samples (render_fused.hip, rv_probe).  0 = march cell by cell like
+ * kernel_march_rays (raymarching.cu:748-801).  Results are identical either way; returns the previous setting. */
+int ngp_render_set_block_skip(int enabled);
 int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
                      uint32_t image_width, const float* aabb, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
                      float dt_gamma, uint32_t max_steps, const float* bg_color3_host,

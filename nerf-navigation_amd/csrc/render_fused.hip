@@ -26,6 +26,9 @@
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 
+#ifndef RF_MIX_BLEND
+#define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
+#endif
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
 #ifndef RF_PROBES_PER_ROUND
@@ -161,6 +164,12 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
                 const uint32_t yz0 = (hy ^ hz) & m, yz1 = (hy1 ^ hz) & m, yz2 = (hy ^ hz1) & m, yz3 = (hy1 ^ hz1) & m;
                 off[0] = (a0 ^ yz0) + b; off[1] = (a1 ^ yz0) + b; off[2] = (a0 ^ yz1) + b; off[3] = (a1 ^ yz1) + b;
                 off[4] = (a0 ^ yz2) + b; off[5] = (a1 ^ yz2) + b; off[6] = (a0 ^ yz3) + b; off[7] = (a1 ^ yz3) + b;
+#ifdef RV_EXPERIMENT_WINDOW        // timing-only build: levels 8..15 gather inside a window of this many bytes per level
+                if (i >= 2) {
+                    #pragma unroll
+                    for (int c = 0; c < 8; c++) off[c] = b + ((off[c] - b) & (uint32_t)(RV_EXPERIMENT_WINDOW - 1));
+                }
+#endif
             } else if (cls.select & bit) {
                 // both kinds in one wave: compute both offsets, select per lane, no branch
                 const bool dense = lv.s1b[i] != 0u;
@@ -192,22 +201,37 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
             for (int c = 0; c < 8; c++) raw[i][c] = rf_row(P, off[c]);
         }
     }
+    // Blend.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):
+    //   w = (wx * wy) * wz in binary32;  results[ch] += w * grid[...]  ==  half(float(result) + float(half(w * float(v))))
+    // RF_MIX_BLEND: v_fma_mixlo/mixhi_f16 compute half(fma32(w, float(v), +0)) in one instruction per feature -- the same
+    // two roundings (binary32 product, then binary16) as the cvt / mul / cvt sequence; the +0 addend only turns a -0 product
+    // into +0, which a sum that starts at +0 cannot tell apart.  The packed-half add is the correctly rounded binary16 sum.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     ngp_h8 out;
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        float r0 = 0.0f, r1 = 0.0f;
+        const f2 wx = {1 - fx[i], fx[i]};
+        const float wy0 = 1 - fy[i], wz0 = 1 - fz[i];
+        const f2 wxy0 = wx * wy0, wxy1 = wx * fy[i];
+        const f2 w[4] = {wxy0 * wz0, wxy1 * wz0, wxy0 * fz[i], wxy1 * fz[i]};     // (y, z) = (0,0) (1,0) (0,1) (1,1)
+        h2 acc = {(_Float16)0.0f, (_Float16)0.0f};
         #pragma unroll
         for (int c = 0; c < 8; c++) {
-            float w = (c & 1) ? fx[i] : 1 - fx[i];
-            w *= (c & 2) ? fy[i] : 1 - fy[i];
-            w *= (c & 4) ? fz[i] : 1 - fz[i];
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const float wc = w[c >> 1][c & 1];
+#if RF_MIX_BLEND
+            uint32_t prod;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(prod) : "v"(wc), "v"(raw[i][c]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(prod) : "v"(wc), "v"(raw[i][c]));
+            acc = acc + __builtin_bit_cast(h2, prod);
+#else
             const h2 v = __builtin_bit_cast(h2, raw[i][c]);
-            r0 = rf_h(r0 + rf_h(w * (float)v.x));
-            r1 = rf_h(r1 + rf_h(w * (float)v.y));
+            const h2 prod = {(_Float16)(wc * (float)v.x), (_Float16)(wc * (float)v.y)};
+            acc = acc + prod;
+#endif
         }
-        out[2 * i] = (_Float16)r0;
-        out[2 * i + 1] = (_Float16)r1;
+        out[2 * i] = acc.x;
+        out[2 * i + 1] = acc.y;
     }
     if (oob) {
         #pragma unroll
@@ -408,6 +432,14 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
 #endif                                        // RV_S = 4 (80 KiB) only fit beside ONE copy of the weights per CU
+#ifndef RV_TILE_ORDER
+#define RV_TILE_ORDER 0                // 1: hand out the 8x8 pixel tiles most expensive first (k_tile_estimate / k_tile_order).
+#endif                                 // A/B on MI355X: 5.25-5.35 ms with, 5.0-5.2 ms without: the frame is bound by L1 tag and
+                                       // VALU throughput, not by its tail, and sorted tiles lose spatial locality.  Kept for scenes
+                                       // with a heavier tail; off by default.
+#ifndef RV_BLOCK_SKIP
+#define RV_BLOCK_SKIP 1                // verified skips through empty 4^3 / 16^3 blocks of the occupancy grid (rv_probe)
+#endif
 #ifndef RV_PATCH_4X4
 #define RV_PATCH_4X4 1                 // each 16-lane column group covers a 4x4 pixel patch
 #endif
@@ -430,6 +462,8 @@ struct rf_frame {
     const uint32_t* coarse;          // [C * (H/4)^3 / 32] words, or null when H is not a power of two >= 4
     uint32_t coarse_words;           // words per cascade level
     uint32_t tile_w;                 // image width in pixels when the rays are a row-major image (8x8 tile order), else 0
+    uint32_t skip;                   // 1: empty 4^3 / 16^3 blocks may be skipped (rv_probe); decided on the host from H, C, bound
+    const uint32_t* tile_order;      // [N/64] 8x8 tiles, most expensive first (k_tile_order), or null
 };
 
 // coarse[level][m] = any fine bit set in Morton block m (64 bits = 8 bytes of the bitfield)
@@ -454,47 +488,167 @@ struct rv_consts {                                     // wave-uniform (SGPRs), 
     const uint8_t* grid;
     __device__ __forceinline__ int mip(int e) const { return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e)); }
 };
+__device__ __forceinline__ float rv_uniform(float v) {     // a wave-uniform value computed by the vector ALU -> SGPR
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 struct rv_view : rv_ray, rv_consts {                   // what rv_probe reads: per-ray VGPRs + uniform SGPRs
     __device__ __forceinline__ rv_view(const rv_ray& r, const rv_consts& k) : rv_ray(r), rv_consts(k) {}
 };
 
-// ngp_march_t::probe with the coarse map in front of the fine bit (same arithmetic, same decisions)
+// One march sample point: everything kernel_march_rays derives from t (raymarching.cu:748-781), same arithmetic.
+struct rv_point {
+    float x, y, z, dt, mip_bound;
+    int level, nx, ny, nz;
+    __device__ __forceinline__ void at(const rv_view& m, float tc) {
+        x = ngp_clampf(m.ox + tc * m.dx, -m.bound, m.bound);
+        y = ngp_clampf(m.oy + tc * m.dy, -m.bound, m.bound);
+        z = ngp_clampf(m.oz + tc * m.dz, -m.bound, m.bound);
+        dt = ngp_clampf(tc * m.dt_gamma, m.dt_min, m.dt_max);
+        int e_pos, e_dt;
+        (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
+        (void)frexpf((dt * m.Hf) * 0.5f, &e_dt);
+        const int lp = m.mip(e_pos), ld = m.mip(e_dt);
+        level = lp > ld ? lp : ld;
+        const float p2 = (float)(1 << level);
+        mip_bound = fminf(p2, m.bound);
+        // 1 / mip_bound without a division per probe: 2^-level is exact and 1 / bound is the same IEEE quotient, computed once
+        const float mip_rbound = (p2 <= m.bound) ? __builtin_ldexpf(1.0f, -level) : m.rbound;
+        nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
+        ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
+        nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
+    }
+    // ray parameter at which the ray leaves this point's cell (raymarching.cu:792-797)
+    __device__ __forceinline__ float cell_exit(const rv_view& m, float tc) const {
+        const float tx = (((((float)nx + 0.5f + 0.5f * copysignf(1.0f, m.dx)) * m.rH) * 2.0f - 1.0f) * mip_bound - x) * m.rdx;
+        const float ty = (((((float)ny + 0.5f + 0.5f * copysignf(1.0f, m.dy)) * m.rH) * 2.0f - 1.0f) * mip_bound - y) * m.rdy;
+        const float tz = (((((float)nz + 0.5f + 0.5f * copysignf(1.0f, m.dz)) * m.rH) * 2.0f - 1.0f) * mip_bound - z) * m.rdz;
+        return tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    // the same for the aligned block of 2^sh cells per axis around the cell (an estimate: only used to choose a skip target)
+    __device__ __forceinline__ float block_exit(const rv_view& m, float tc, int sh) const {
+        const float bs = (float)(1 << sh);
+        const float tx = ((((((float)(nx >> sh) + 0.5f + 0.5f * copysignf(1.0f, m.dx)) * bs) * m.rH) * 2.0f - 1.0f) * mip_bound - x) * m.rdx;
+        const float ty = ((((((float)(ny >> sh) + 0.5f + 0.5f * copysignf(1.0f, m.dy)) * bs) * m.rH) * 2.0f - 1.0f) * mip_bound - y) * m.rdy;
+        const float tz = ((((((float)(nz >> sh) + 0.5f + 0.5f * copysignf(1.0f, m.dz)) * bs) * m.rH) * 2.0f - 1.0f) * mip_bound - z) * m.rdz;
+        return tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+};
+
+// ngp_march_t::probe with the coarse map in front of the fine bit, and verified skips through empty blocks.
+//
+// The reference leaves an empty cell by stepping t += dt until t passes the cell's exit (raymarching.cu:792-801).  The
+// step depends on t alone, so the points t_0 = near, t_{k+1} = t_k + dt(t_k) form a fixed lattice per ray; the reference
+// tests the first lattice point in every cell that holds one, and every lattice point of an occupied cell is a sample.
+// When the whole 4^3 (or 16^3) block around an empty cell is empty, those tests can only fail, so the march may jump over
+// them -- provided it rejoins the reference's sequence of tested points exactly.  It does so as follows (r = current
+// point, all in the reference's own arithmetic):
+//   1. move along the lattice to a point s short of the block's exit by a guard distance (constant step: in closed form,
+//      rv_lattice_jump; dt_gamma > 0: a bounded walk);
+//   2. evaluate s as the reference would (level, cell): s must lie in the same block at the same level.  Cell indices are
+//      monotone in t on every axis, so every lattice point between r and s then lies in that block as well, and block
+//      alignment with the cascade boundaries (H a power of two >= 64, bound a power of two or a single cascade: decided
+//      on the host, F.skip) keeps those points on the same level: whatever the reference tested in between was empty;
+//   3. take the reference's step from s to the first lattice point a beyond the exit e(s) of s's cell.  The reference
+//      arrives in that cell at some lattice point p (p <= s, or the point after s when s sits on the cell's entry face)
+//      and steps from there beyond e(p).  e(p) and e(s) measure the same face; they differ by rounding only, by less than
+//      the per-ray bound M (see rv_skip_margin).  If no lattice point lies within M of e(s), both steps end on the same
+//      point a, which is therefore a point the reference tests: the skip is accepted and the march continues from a;
+//   4. in every other case the probe takes the reference's ordinary one-cell step from r.
+// The per-op kernels (raymarching.hip) never skip; tests/test_gpu_fullsize.py checks per-ray equality against them.
+// Lattice points of a CONSTANT step inside one binade are equally spaced.  With u the binade's ulp, t = T u and
+// dt = (c + f) u, |f| < 1/2, the sum t + dt rounds to (T + c) u whatever T is, as long as it stays below the binade's end:
+// k steps from t land exactly on t + k (c u), and c u is what one real step adds.  (|f| = 1/2 would round to even and
+// alternate; it is detected from the step's rounding error and not used.)  Returns the lattice point reached from t by
+// one real step plus as many whole steps as stay below min(lim, end of t's binade): every operation here is exact.
+__device__ __forceinline__ float rv_lattice_jump(float t, float dtc, float lim) {
+    const float t1 = t + dtc;                          // the reference's own step
+    const float du = t1 - t;                           // exact (Sterbenz): what that step added
+    int e;
+    (void)frexpf(t, &e);                               // t in [2^(e-1), 2^e), ulp 2^(e-24)
+    const float end = fminf(lim, __builtin_ldexpf(1.0f, e));
+    const float err = dtc - du;                        // exact: rounding error of t + dtc
+    if (!(t1 < end) || !(du > 0.0f) || fabsf(err) == __builtin_ldexpf(1.0f, e - 25)) return t1;
+    // j <= (end - t1) / du - 1 keeps t1 + j du below `end` whatever the rounding of the estimate (relative error ~1e-6)
+    const float j = floorf((end - t1) * __builtin_amdgcn_rcpf(du)) - 1.0f;
+    return j > 0.0f ? t1 + j * du : t1;                // j du < 2^(e-1) is a multiple of u: both operations exact
+}
+
+#ifndef RV_SKIP_WALK
+#define RV_SKIP_WALK 32
+#endif
+// The 64 cells of a 4^3 block are one aligned 64-bit word of the bitfield (Morton order).  A ray tests dozens of lattice
+// points per block, so the word it last loaded stays in registers: one 8-byte load per block entered instead of one byte
+// load per test.  Under load a dependent global load costs the march thousands of cycles (it queues behind the gathers of
+// the 15 other waves of the CU); this takes almost all of them off the march's critical path.
+struct rv_block_cache { uint32_t blk = 0xffffffffu, lo = 0, hi = 0; };
+
+template <bool SKIP>
 __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
-                                         float& t, float& x, float& y, float& z, float& dt) {
+                                         float M, rv_block_cache& bc, float& t, float& x, float& y, float& z, float& dt
+#ifdef RV_COUNTERS
+                                         , int* rv_dbg_ptr
+#endif
+                                         ) {
     const rv_view m(ray, k);
     const float tc = t;
-    x = ngp_clampf(m.ox + tc * m.dx, -m.bound, m.bound);
-    y = ngp_clampf(m.oy + tc * m.dy, -m.bound, m.bound);
-    z = ngp_clampf(m.oz + tc * m.dz, -m.bound, m.bound);
-    dt = ngp_clampf(tc * m.dt_gamma, m.dt_min, m.dt_max);
-    int e_pos, e_dt;
-    (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
-    (void)frexpf((dt * m.Hf) * 0.5f, &e_dt);
-    const int lp = m.mip(e_pos), ld = m.mip(e_dt);
-    const int level = lp > ld ? lp : ld;
-    const float p2 = (float)(1 << level);
-    const float mip_bound = fminf(p2, m.bound);
-    // 1 / mip_bound without a division per probe: 2^-level is exact and 1 / bound is the same IEEE quotient, computed once
-    const float mip_rbound = (p2 <= m.bound) ? __builtin_ldexpf(1.0f, -level) : m.rbound;
-    const int nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
-    const int ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
-    const int nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
-    const uint32_t mort = ngp_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    rv_point r;
+    r.at(m, tc);
+    x = r.x; y = r.y; z = r.z; dt = r.dt;
+    const uint32_t mort = ngp_morton3((uint32_t)r.nx, (uint32_t)r.ny, (uint32_t)r.nz);
     bool occ;
     bool maybe = true;
+    uint32_t sw = 0;
     if (lds_coarse) {
         const uint32_t blk = mort >> 6;
-        maybe = (lds_coarse[(uint32_t)level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u;
+        maybe = (lds_coarse[(uint32_t)r.level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u;
+        sw = (uint32_t)r.level * coarse_words + ((blk >> 6) << 1);       // the 64 coarse bits of the 16^3 block: 2 words
+#ifdef RV_COUNTERS
+        *rv_dbg_ptr = maybe ? 0 : ((lds_coarse[sw] | lds_coarse[sw + 1]) == 0u ? 2 : 1);
+#endif
     }
-    if (maybe) {
-        const uint32_t index = (uint32_t)((float)level * m.H3 + (float)mort);
+    if (!maybe) occ = false;
+    else if (lds_coarse) {
+        // with a coarse map the cell index level * H^3 + morton is exact in binary32 (host: C * H^3 <= 2^24), so the
+        // reference's bit (raymarching.cu:783-784) is bit (morton & 63) of word level * H^3 / 64 + (morton >> 6)
+        const uint32_t gblk = (uint32_t)r.level * (coarse_words << 5) + (mort >> 6);
+        if (gblk != bc.blk) {
+            const uint2 w = reinterpret_cast<const uint2*>(m.grid)[gblk];
+            bc.blk = gblk; bc.lo = w.x; bc.hi = w.y;
+        }
+        occ = (((mort & 32u) ? bc.hi : bc.lo) >> (mort & 31u)) & 1u;
+    } else {
+        const uint32_t index = (uint32_t)((float)r.level * m.H3 + (float)mort);
         occ = (m.grid[index >> 3] >> (index & 7u)) & 1u;
-    } else occ = false;
+    }
     if (occ) return true;
-    const float tx = (((((float)nx + 0.5f + 0.5f * copysignf(1.0f, m.dx)) * m.rH) * 2.0f - 1.0f) * mip_bound - x) * m.rdx;
-    const float ty = (((((float)ny + 0.5f + 0.5f * copysignf(1.0f, m.dy)) * m.rH) * 2.0f - 1.0f) * mip_bound - y) * m.rdy;
-    const float tz = (((((float)nz + 0.5f + 0.5f * copysignf(1.0f, m.dz)) * m.rH) * 2.0f - 1.0f) * mip_bound - z) * m.rdz;
-    const float tt = tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    const float tt = r.cell_exit(m, tc);
+    if (SKIP && lds_coarse && !maybe) {
+        const int sh = ((lds_coarse[sw] | lds_coarse[sw + 1]) == 0u) ? 4 : 2;
+        const float tb = r.block_exit(m, tc, sh);
+        const float target = tb - (2.0f * ngp_clampf(tb * m.dt_gamma, m.dt_min, m.dt_max) + M);
+        if (target > tt) {                             // false when M is inf or NaN: such rays never skip
+            // step 1: s only has to be a lattice point inside the block, the further the better
+            float ts = tc;
+            int guard = 0;
+            if (m.dt_gamma == 0.0f) ts = rv_lattice_jump(tc, ngp_clampf(0.0f, m.dt_min, m.dt_max), target);
+            else {
+                do {                                   // a varying step has no closed form: walk, at most RV_SKIP_WALK steps
+                    ts += ngp_clampf(ts * m.dt_gamma, m.dt_min, m.dt_max);
+                } while (ts < target && ++guard < RV_SKIP_WALK);
+            }
+            rv_point q;
+            q.at(m, ts);
+            if (q.level == r.level && (q.nx >> sh) == (r.nx >> sh) && (q.ny >> sh) == (r.ny >> sh) && (q.nz >> sh) == (r.nz >> sh)) {
+                const float te = q.cell_exit(m, ts);
+                float ta = ts, tp;
+                do {
+                    tp = ta;
+                    ta += ngp_clampf(ta * m.dt_gamma, m.dt_min, m.dt_max);
+                } while (ta < te && ++guard < NGP_SKIP_GUARD);
+                if ((te - tp) > M && (ta - te) > M && guard < NGP_SKIP_GUARD) { t = ta; return false; }
+            }
+        }
+    }
     float tn = tc;
     int guard = 0;
     do {
@@ -502,6 +656,17 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
     } while (tn < tt && ++guard < NGP_SKIP_GUARD);
     t = tn;
     return false;
+}
+
+// Bound on how far two evaluations of one cell face's ray parameter (rv_point::cell_exit from two points of the cell)
+// can differ.  cell_exit = t + (plane - x(t)) * (1/d): the plane is exact (H and the cascade bound are powers of two),
+// x(t) = o + t d carries two roundings of magnitude <= 2^-24 (|o| + 2 |x|) <= 2^-24 (|o| + 2 bound), the difference one more,
+// the product with 1/d two more, the final sum one of 2^-24 t.  The bound below is 8x that estimate; a ray with a
+// vanishing direction component gets M = inf and never skips.
+__device__ __forceinline__ float rv_skip_margin(const rv_ray& r, float bound, float far) {
+    const float pos = fmaxf(fabsf(r.ox), fmaxf(fabsf(r.oy), fabsf(r.oz))) + 4.0f * bound;
+    const float rd = fmaxf(fabsf(r.rdx), fmaxf(fabsf(r.rdy), fabsf(r.rdz)));
+    return 4.8e-7f * (pos * rd + fabsf(far));           // 8 * 2^-24 = 4.8e-7
 }
 
 __device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int f, int lane) { return lds_w[f * 64 + lane]; }
@@ -584,9 +749,11 @@ __device__ __forceinline__ void rv_activate(const rf_params& P, float& sigma, fl
 // queue index -> ray id.  With tile_w set (rays are a row-major image whose width and height are multiples of 8)
 // consecutive queue indices walk 8x8 pixel tiles, so the 64 lanes of a wave start on a compact patch of the image
 // and their gathers share cache lines; otherwise the identity.
-__device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w) {
+__device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w, const uint32_t* __restrict__ tile_order) {
     if (tile_w == 0) return idx;
-    const uint32_t tile = idx >> 6, in = idx & 63u, tiles_x = tile_w >> 3;
+    uint32_t tile = idx >> 6;
+    const uint32_t in = idx & 63u, tiles_x = tile_w >> 3;
+    if (tile_order) tile = tile_order[tile];
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
 #if RV_PATCH_4X4
     // lanes 16p..16p+15 (one MFMA column tile, one gather instruction group) cover a compact 4x4 pixel patch
@@ -638,13 +805,14 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
     const _Float16* wave_sh = lds_sh + wave * 64 * 16;
 
     // wave-uniform march constants (ngp_march_t::setup's formulas), kept out of the per-ray state
+    // float conversions and divisions run on the vector ALU even for uniform inputs; rv_uniform moves the results to SGPRs
     rv_consts K;
-    K.bound = P.bound; K.rbound = 1.0f / P.bound; K.dt_gamma = F.dt_gamma;
-    K.Hf = (float)F.H; K.Cf = (float)F.C; K.Hm1 = (float)(F.H - 1);
-    K.rH = 1.0f / K.Hf;
-    K.H3 = (float)(F.H * F.H * F.H);
-    K.dt_min = (2.0f * 1.7320508075688772f) / (float)F.max_steps;
-    K.dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf;
+    K.bound = P.bound; K.rbound = rv_uniform(1.0f / P.bound); K.dt_gamma = F.dt_gamma;
+    K.Hf = rv_uniform((float)F.H); K.Cf = rv_uniform((float)F.C); K.Hm1 = rv_uniform((float)(F.H - 1));
+    K.rH = rv_uniform(1.0f / K.Hf);
+    K.H3 = rv_uniform((float)(F.H * F.H * F.H));
+    K.dt_min = rv_uniform((2.0f * 1.7320508075688772f) / (float)F.max_steps);
+    K.dt_max = rv_uniform(((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf);
     K.grid = F.bitfield;
 
     bool active = false;
@@ -653,6 +821,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
     float t = 0, last_t = 0, near = 0, far = 0;
     float ws = 0, dacc = 0, cr = 0, cg = 0, cb = 0, tcomp = 0;
     bool exhausted = false;
+    rv_block_cache bc;
     uint32_t n_samples_local = 0;
 
     for (;;) {
@@ -667,7 +836,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
                 if (!active) {
                     const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                     if (idx < F.N) {
-                        ray = rv_ray_of(idx, F.tile_w);
+                        ray = rv_ray_of(idx, F.tile_w, F.tile_order);
                         const float* o = F.rays_o + 3ull * ray;
                         const float* d = F.rays_d + 3ull * ray;
                         ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
@@ -695,7 +864,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
             int probes = 0;
             for (;;) {
                 if (!(t < far && nsamp < F.max_steps)) { ended = true; break; }
-                if (rv_probe(m, K, lds_coarse, F.coarse_words, t, x, y, z, dt)) { has = true; break; }
+                if (rv_probe<false>(m, K, lds_coarse, F.coarse_words, 0.0f, bc, t, x, y, z, dt)) { has = true; break; }
                 if (++probes >= RF_PROBES_PER_ROUND) break;
             }
             if (has) {
@@ -775,6 +944,79 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
 #if RV_S > 1
 static constexpr uint32_t RV_LDS_SMP = RV_WAVES * 64 * RV_S * 20;      // per sample: float4 (x, y, z, dt) + float d1
 
+// ---------------------------------------------------------------------------
+// Tile order.  A frame's rays differ a lot in cost (0 to a few hundred samples) and a lane only ever sees two or three
+// of them, so the order in which the queue hands them out decides how long the last waves run alone.  Longest first:
+// k_tile_estimate marches the centre ray of every 8x8 pixel tile through the occupancy grid and counts its samples (no
+// field evaluation); k_tile_order sorts the tiles by that count, descending (counting sort, one workgroup).  The frame
+// kernel maps queue position -> tile through the table.  Results do not depend on the order (tests: order invariance).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_estimate(rf_frame F, float bound, uint32_t n_tiles, uint32_t* __restrict__ est) {
+    const uint32_t tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t tiles_x = F.tile_w >> 3;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t ray = (ty * 8 + 4) * F.tile_w + tx * 8 + 4;
+    const float* o = F.rays_o + 3ull * ray;
+    const float* d = F.rays_d + 3ull * ray;
+    float near, far;
+    ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
+    rv_ray m;
+    m.ox = o[0]; m.oy = o[1]; m.oz = o[2];
+    m.dx = d[0]; m.dy = d[1]; m.dz = d[2];
+    m.rdx = 1.0f / m.dx; m.rdy = 1.0f / m.dy; m.rdz = 1.0f / m.dz;
+    rv_consts K;
+    K.bound = bound; K.rbound = 1.0f / bound; K.dt_gamma = F.dt_gamma;
+    K.Hf = (float)F.H; K.Cf = (float)F.C; K.Hm1 = (float)(F.H - 1);
+    K.rH = 1.0f / K.Hf;
+    K.H3 = (float)(F.H * F.H * F.H);
+    K.dt_min = (2.0f * 1.7320508075688772f) / (float)F.max_steps;
+    K.dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf;
+    K.grid = F.bitfield;
+    const float M = F.skip ? rv_skip_margin(m, bound, far) : __builtin_inff();
+    float t = near;
+    uint32_t n = 0;
+    int probes = 0;
+    rv_block_cache bc;
+    while (t < far && n < 1023u && probes < 4096) {
+        float x, y, z, dt;
+#ifdef RV_COUNTERS
+        int pc;
+        if (rv_probe<true>(m, K, F.coarse, F.coarse_words, M, bc, t, x, y, z, dt, &pc)) { t += dt; n++; }
+#else
+        if (rv_probe<true>(m, K, F.coarse, F.coarse_words, M, bc, t, x, y, z, dt)) { t += dt; n++; }
+#endif
+        probes++;
+    }
+    est[tile] = n;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ est, uint32_t n_tiles, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tiles; i += 1024) atomicAdd(&hist[1023u - est[i]], 1u);      // bin 0 = most samples
+    __syncthreads();
+    // exclusive prefix sum over the 1024 bins: wave scan, then the 16 wave totals
+    const uint32_t v = hist[tid];
+    uint32_t inc = v;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(inc, off, 64);
+        if ((int)(tid & 63u) >= off) inc += up;
+    }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) base += wsum[w];
+    __syncthreads();
+    hist[tid] = base + inc - v;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tiles; i += 1024) order[atomicAdd(&hist[1023u - est[i]], 1u)] = i;
+}
+
 // The persistent loop of k_render_frame_multi.  FIXED selects compile-time iteration classes for the reference's grid
 // (iteration 0 dense, 1 mixed, 2 and 3 hashed: 16 levels from 16^3 at 2^19 rows per level): with the classes constant the
 // encoder is straight-line code and all 32 gathers of a tile are in flight together; with run-time classes the compiler
@@ -785,6 +1027,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                                               float4* lds_smp, float* lds_d1, const uint32_t* lds_coarse) {
     const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the same, known to be uniform
 
     _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;
     const _Float16* wave_sh = lds_sh + wave * 64 * 16;
@@ -792,13 +1035,14 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     float* my_d1 = lds_d1 + (wave * 64 + lane) * RV_S;
     float4* wave_smp = lds_smp + wave * 64 * RV_S;
 
+    // float conversions and divisions run on the vector ALU even for uniform inputs; rv_uniform moves the results to SGPRs
     rv_consts K;
-    K.bound = P.bound; K.rbound = 1.0f / P.bound; K.dt_gamma = F.dt_gamma;
-    K.Hf = (float)F.H; K.Cf = (float)F.C; K.Hm1 = (float)(F.H - 1);
-    K.rH = 1.0f / K.Hf;
-    K.H3 = (float)(F.H * F.H * F.H);
-    K.dt_min = (2.0f * 1.7320508075688772f) / (float)F.max_steps;
-    K.dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf;
+    K.bound = P.bound; K.rbound = rv_uniform(1.0f / P.bound); K.dt_gamma = F.dt_gamma;
+    K.Hf = rv_uniform((float)F.H); K.Cf = rv_uniform((float)F.C); K.Hm1 = rv_uniform((float)(F.H - 1));
+    K.rH = rv_uniform(1.0f / K.Hf);
+    K.H3 = rv_uniform((float)(F.H * F.H * F.H));
+    K.dt_min = rv_uniform((2.0f * 1.7320508075688772f) / (float)F.max_steps);
+    K.dt_max = rv_uniform(((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf);
     K.grid = F.bitfield;
 
     bool active = false;
@@ -807,7 +1051,17 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     float t = 0, last_t = 0, near = 0, far = 0;
     float ws = 0, dacc = 0, cr = 0, cg = 0, cb = 0, tcomp = 0;
     bool exhausted = false;
-    uint32_t n_samples_local = 0;
+    rv_block_cache bc;                                 // bitfield word of the block the ray last tested (block ids are global: stays valid across rays)
+    uint32_t n_samples_local = 0, n_tiles = 0;
+#ifdef RV_COUNTERS
+    uint32_t n_rounds = 0, n_trips = 0, n_probe[3] = {0, 0, 0};
+    unsigned long long c_refill = 0, c_march = 0, c_tiles = 0, c_comp = 0;
+    const unsigned long long c_start = __builtin_readcyclecounter();
+    unsigned long long c_last = c_start;
+#define RV_TICK(acc) { const unsigned long long c_now = __builtin_readcyclecounter(); acc += c_now - c_last; c_last = c_now; }
+#else
+#define RV_TICK(acc)
+#endif
 
     for (;;) {
         if (!exhausted) {
@@ -820,7 +1074,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 if (!active) {
                     const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                     if (idx < F.N) {
-                        ray = rv_ray_of(idx, F.tile_w);
+                        ray = rv_ray_of(idx, F.tile_w, F.tile_order);
                         const float* o = F.rays_o + 3ull * ray;
                         const float* d = F.rays_d + 3ull * ray;
                         ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
@@ -840,19 +1094,49 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             }
         }
         if (__ballot(active) == 0ull) break;
+        RV_TICK(c_refill)
 
         // ---- march: up to RV_S samples per lane within one shared probe budget ----
         int cnt = 0;
         bool ended = false;
+#ifdef RV_COUNTERS
+        n_rounds++;
+#endif
         if (active) {
+            // The ray's constants live across the field evaluation, where every register is taken, so the allocator keeps them
+            // in scratch; without this copy it reloads them at each use inside the probe loop (10 scratch loads per probe on
+            // the march's critical path).  The copy is defined here and dies with the loop: one reload per round.
+            rv_ray mr = m;
+            float far_r = far;
+            asm("" : "+v"(mr.ox), "+v"(mr.oy), "+v"(mr.oz), "+v"(mr.dx), "+v"(mr.dy), "+v"(mr.dz),
+                     "+v"(mr.rdx), "+v"(mr.rdy), "+v"(mr.rdz), "+v"(far_r));
+            // the same for the march constants: uniform, but the scalar registers are all taken, so they live in (spilled)
+            // vector registers; a copy per round keeps every memory access out of the probe loop
+            rv_consts Kr = K;
+            asm("" : "+v"(Kr.Hf), "+v"(Kr.Hm1), "+v"(Kr.Cf), "+v"(Kr.rH), "+v"(Kr.dt_min), "+v"(Kr.dt_max), "+v"(Kr.rbound), "+v"(Kr.H3));
+            const float M = F.skip ? rv_skip_margin(mr, K.bound, far_r) : __builtin_inff();
+            // this lane's slots, recomputed from the lane id (2 VALU) rather than kept across the field evaluation in scratch
+            const uint32_t slot0 = ((uint32_t)wave_s * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) * RV_S;
+            float4* const smp_w = lds_smp + slot0;
+            float* const d1_w = lds_d1 + slot0;
             int probes = 0;
             for (;;) {
-                if (!(t < far && nsamp < F.max_steps)) { ended = true; break; }
+#ifdef RV_COUNTERS
+                n_trips = __builtin_amdgcn_readfirstlane(n_trips) + 1;
+#endif
+                if (!(t < far_r && nsamp < F.max_steps)) { ended = true; break; }
                 float x, y, z, dt;
-                if (rv_probe(m, K, lds_coarse, F.coarse_words, t, x, y, z, dt)) {
+#ifdef RV_COUNTERS
+                int pc = 0;
+                const bool hit = rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt, &pc);
+                n_probe[pc]++;
+                if (hit) {
+#else
+                if (rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt)) {
+#endif
                     t += dt;
-                    my_smp[cnt] = make_float4(x, y, z, dt);
-                    my_d1[cnt] = t - last_t;
+                    smp_w[cnt] = make_float4(x, y, z, dt);
+                    d1_w[cnt] = t - last_t;
                     last_t = t;
                     nsamp++;
                     if (++cnt == RV_S) break;
@@ -867,6 +1151,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        RV_TICK(c_march)
         // ---- field evaluation: for each group of 16 rays, tile k = their k-th samples ----
         #pragma unroll 1
         for (int p = 0; p < 4; p++) {
@@ -880,6 +1165,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 if (__ballot(ccol > k) == 0ull) break;   // counts only shrink with k
                 float4 q = wave_smp[src * RV_S + k];
                 if (!(ccol > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);   // column without a k-th sample: harmless dummy
+                n_tiles++;
                 float a, b, c, d;
                 rv_field_tile(P, lv, cls, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
                 if (g == 0 && ccol > k) {                // the half-precision network outputs replace (x, y) of the slot
@@ -894,6 +1180,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        RV_TICK(c_tiles)
         // ---- composite this lane's samples in order (kernel_composite_rays arithmetic, raymarching.cu:865-896) ----
         bool done = false;
         for (int k = 0; k < cnt; k++) {
@@ -923,11 +1210,23 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             if (nsamp > 0) atomicAdd(F.stats + 2, 1u);
             active = false;
         }
+        RV_TICK(c_comp)
     }
     uint32_t tot = n_samples_local;
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(F.stats, tot);
+    if (lane == 0 && n_tiles) atomicAdd(F.stats + 3, n_tiles);
+#ifdef RV_COUNTERS
+    if (lane == 0) { atomicAdd(F.queue + 1, n_rounds); atomicAdd(F.queue + 2, n_trips); }
+    atomicAdd(F.queue + 3, n_probe[0]); atomicAdd(F.queue + 4, n_probe[1]); atomicAdd(F.queue + 5, n_probe[2]);
+    if (lane == 0) {                                   // cycle counters: u64 at bytes 32.. of the workspace header
+        unsigned long long* c = reinterpret_cast<unsigned long long*>(F.queue + 8);
+        const unsigned long long c_total = __builtin_readcyclecounter() - c_start;
+        atomicAdd(c + 0, c_refill); atomicAdd(c + 1, c_march); atomicAdd(c + 2, c_tiles); atomicAdd(c + 3, c_comp);
+        atomicAdd(c + 4, c_total); atomicMax(c + 5, c_total); atomicMax(c + 6, ~c_total);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_multi(rf_params P, rf_frame F) {
@@ -973,9 +1272,17 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
 
 static inline bool rv_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
+static int rv_block_skip_enabled = 1;
+extern "C" int ngp_render_set_block_skip(int enabled) {
+    const int old = rv_block_skip_enabled;
+    rv_block_skip_enabled = enabled ? 1 : 0;
+    return old;
+}
+
+static constexpr size_t RV_WS_COARSE = 128, RV_WS_TILES = 128 + 48 * 1024;
 extern "C" size_t ngp_render_frame_workspace(uint32_t N) {
-    (void)N;
-    return 64 + 48 * 1024;                                             // ray queue + coarse occupancy map (<= 48 KiB)
+    // ray queue | coarse occupancy map (<= 48 KiB) | per-tile estimates and tile order (one u32 each per 64 rays)
+    return RV_WS_TILES + 2 * sizeof(uint32_t) * (size_t)ngp_div_up(N, 64u);
 }
 
 extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
@@ -986,11 +1293,11 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     rf_params P;
     int rc = rf_fill_params("render_frame", field_host, P);
     if (rc != NGP_OK) return rc;
-    NGP_REQUIRE(stats && workspace && workspace_bytes >= 64, "render_frame: stats / workspace missing");
+    NGP_REQUIRE(stats && workspace && workspace_bytes >= 128, "render_frame: stats / workspace missing");
     NGP_REQUIRE(aabb_host && bg_color3_host, "render_frame: aabb / bg_color are host pointers and must not be null");
     NGP_REQUIRE(C >= 1 && C <= 16 && Hgrid >= 1 && Hgrid <= 1024 && max_steps >= 1, "render_frame: bad C/H/max_steps");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(workspace, 0, 64, s) != hipSuccess)
+    if (hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(workspace, 0, RV_WS_COARSE, s) != hipSuccess)
         return ngp_fail(NGP_ELAUNCH, "render_frame: memset failed");
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && bitfield && image && depth && weights_sum, "render_frame: null pointer");
@@ -1007,7 +1314,7 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     if (hint >= 8 && hint % 8 == 0 && N % hint == 0 && (N / hint) % 8 == 0) F.tile_w = hint;
 
     // coarse occupancy (needs Morton blocks: H a power of two >= 4) in the workspace, then in LDS
-    F.coarse = nullptr; F.coarse_words = 0;
+    F.coarse = nullptr; F.coarse_words = 0; F.skip = 0;
     static_assert(sizeof(rf_lane_levels) * 4 == RV_LDS_LV, "LDS carve of the level table");
     size_t lds = RV_LDS_W + RV_LDS_SH + RV_LDS_LV;
 #if RV_S > 1
@@ -1018,16 +1325,32 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
 #endif
     const uint64_t blocks_per_level = (uint64_t)Hgrid * Hgrid * Hgrid / 64;
     const uint64_t coarse_bytes = (uint64_t)C * blocks_per_level / 8;
-    if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && coarse_bytes <= 48 * 1024 &&
-        workspace_bytes >= 64 + coarse_bytes && (reinterpret_cast<uintptr_t>(bitfield) & 7u) == 0) {
-        uint32_t* coarse = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + 64);
+    // (C * H^3 <= 2^24: the reference forms the cell index in binary32, raymarching.cu:783; beyond that it rounds)
+    if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && coarse_bytes <= 48 * 1024 && (uint64_t)C * Hgrid * Hgrid * Hgrid <= (1ull << 24) &&
+        workspace_bytes >= RV_WS_COARSE + coarse_bytes && (reinterpret_cast<uintptr_t>(bitfield) & 7u) == 0) {
+        uint32_t* coarse = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + RV_WS_COARSE);
         const uint32_t n_blocks_total = (uint32_t)(C * blocks_per_level);
         hipLaunchKernelGGL(k_build_coarse, dim3(ngp_div_up(n_blocks_total / 32, 256)), dim3(256), 0, s, bitfield, n_blocks_total, coarse);
         F.coarse = coarse;
         F.coarse_words = (uint32_t)(blocks_per_level / 32);
         lds += coarse_bytes;
+        // block skipping needs the 16^3 blocks aligned with the cascade boundaries (cells H/4 and 3H/4 of the next level) and
+        // every level's half-width a power of two: H a power of two >= 64, and bound a power of two unless there is one cascade
+        int e;
+        F.skip = (rv_block_skip_enabled && Hgrid >= 64 && (C == 1 || frexpf(field_host->bound, &e) == 0.5f)) ? 1u : 0u;
     }
     NGP_REQUIRE(lds <= 160 * 1024, "render_frame: LDS carve exceeds 160 KiB");
+    F.tile_order = nullptr;
+#if RV_TILE_ORDER
+    if (F.tile_w && F.coarse && workspace_bytes >= ngp_render_frame_workspace(N)) {
+        const uint32_t n_tiles = N / 64;
+        uint32_t* est = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + RV_WS_TILES);
+        uint32_t* order = est + n_tiles;
+        hipLaunchKernelGGL(k_tile_estimate, dim3(ngp_div_up(n_tiles, 256u)), dim3(256), 0, s, F, P.bound, n_tiles, est);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, est, n_tiles, order);
+        F.tile_order = order;
+    }
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

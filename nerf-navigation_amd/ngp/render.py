@@ -130,7 +130,7 @@ class NGPRenderer(nn.Module):
     @torch.no_grad()
     def render_fused(self, rays_o, rays_d, dt_gamma=0, bg_color=None, max_steps=1024, image_width=0, **kwargs):
         """Inference only.  Returns image / depth / weights_sum like run_cuda plus `stats`, a 4-int device tensor:
-        [ray-samples evaluated, rays that hit the max_steps cap, rays with >= 1 sample, 0].
+        [ray-samples evaluated, rays that hit the max_steps cap, rays with >= 1 sample, 16-column MFMA tiles evaluated].
         image_width: width of the image when the rays are a full row-major image (enables 8x8 tile traversal)."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
@@ -151,7 +151,10 @@ class NGPRenderer(nn.Module):
                                       _hip.ptr(self.density_bitfield), self.cascade, self.grid_size, dt_gamma, max_steps, bg,
                                       _hip.ptr(image), _hip.ptr(depth), _hip.ptr(weights_sum), _hip.ptr(stats),
                                       _hip.ptr(ws), ws.numel(), _hip.stream()), "render_frame")
-        return {"image": image.view(*prefix, 3), "depth": depth.view(*prefix), "weights_sum": weights_sum, "stats": stats}
+        out = {"image": image.view(*prefix, 3), "depth": depth.view(*prefix), "weights_sum": weights_sum, "stats": stats}
+        if kwargs.get("return_workspace"):
+            out["workspace"] = ws                          # debug builds (-DRV_COUNTERS) leave counters behind the ray queue
+        return out
 
     # ------------------------------------------------------------------------------------------------------------
     # fixed-step path (nav loop)

@@ -108,8 +108,8 @@ def test_fused_frame_full_size_properties(full, dev):
     a = ren.render_fused(o[None], d[None], bg_color=1, image_width=RES)
     b = ren.render_fused(o[None], d[None], bg_color=1, image_width=RES)
     c = ren.render_fused(o[None], d[None], bg_color=1, image_width=0)                 # no tile hint: other traversal order
-    assert torch.equal(a["image"], b["image"]) and torch.equal(a["stats"], b["stats"])
-    assert torch.equal(a["image"], c["image"]) and torch.equal(a["stats"], c["stats"])
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["stats"][:3], b["stats"][:3])
+    assert torch.equal(a["image"], c["image"]) and torch.equal(a["stats"][:3], c["stats"][:3])   # [3] = tiles: order-dependent
     st = a["stats"].cpu().numpy()
     assert st[1] == 0 and 20_000_000 < st[0] < 40_000_000
     img = a["image"][0]
@@ -124,3 +124,86 @@ def test_fused_frame_full_size_properties(full, dev):
     assert float((ref["image"][0] - img).abs().max()) < 5e-3
     consumed_upper = sum(k for _, _, k in tr)                                         # marched (>= composited) samples of the loop
     assert st[0] <= consumed_upper <= 1.1 * st[0]
+
+
+def _constant_density_renderer(dev, grid, density_scale):
+    """All-zero networks: sigma = density_scale * exp(0) everywhere, rgb = sigmoid(0).  With a small density_scale no ray
+    saturates, so every marched sample is composited and a ray's weights_sum is a strictly increasing function of its
+    sample set: one sample more or less anywhere changes it."""
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    field = NGPFieldFF(bound=W.BOUND, density_scale=density_scale).to(dev)
+    with torch.no_grad():
+        field.sigma_net.weights.zero_()
+        field.color_net.weights.zero_()
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_scale=density_scale, density_thresh=0.5).to(dev).eval()
+    ren.load_density_grid(grid)
+    return ren
+
+
+def _scene_grid(W, oracle, scene):
+    from _util import blob_bitfield
+    if scene == "sring":
+        return (W.density_grid() > 10.0).astype(np.float32)
+    return blob_bitfield(oracle, 2, 128, seed=7, n_blobs=60, bound=W.BOUND)[1]
+
+
+@pytest.mark.parametrize("scene,dt_gamma,pose", [("sring", 0.0, 1), ("sring", 1.0 / 128, 5), ("blobs", 0.0, 3), ("blobs", 1.0 / 256, 6)])
+def test_block_skipping_changes_nothing(full, oracle, dev, scene, dt_gamma, pose):
+    """The fused kernel jumps through empty 4^3 / 16^3 blocks of the occupancy grid (render_fused.hip rv_probe).  With the
+    switch off it marches cell by cell like the reference.  Both ways, 640,000 rays: bit-identical outputs."""
+    import ngp_hip
+    W = full["W"]
+    ren = _constant_density_renderer(dev, _scene_grid(W, oracle, scene), 1e-3)
+    o, d = W.get_rays(W.orbit_pose(pose), W.intrinsics(RES, RES), RES, RES)
+    o, d = t(o, dev), t(d, dev)
+    L = ngp_hip.lib()
+    try:
+        assert L.ngp_render_set_block_skip(0) == 1
+        plain = ren.render_fused(o[None], d[None], bg_color=1, dt_gamma=dt_gamma, image_width=RES)
+        torch.cuda.synchronize()
+    finally:
+        L.ngp_render_set_block_skip(1)
+    skip = ren.render_fused(o[None], d[None], bg_color=1, dt_gamma=dt_gamma, image_width=RES)
+    st = skip["stats"].cpu().numpy()
+    assert st[1] == 0 and st[0] > 5_000_000 and float(skip["weights_sum"].max()) < 0.5   # nothing saturates: every sample counts
+    assert torch.equal(skip["stats"][:3], plain["stats"][:3])
+    for key in ("weights_sum", "depth", "image"):
+        assert torch.equal(skip[key], plain[key]), f"{key}: {int((skip[key] != plain[key]).sum())} values differ"
+    # and the real field (saturating rays, early termination) on the same rays
+    a = full["ren"].render_fused(o[None], d[None], bg_color=1, dt_gamma=dt_gamma, image_width=RES)
+    try:
+        L.ngp_render_set_block_skip(0)
+        b = full["ren"].render_fused(o[None], d[None], bg_color=1, dt_gamma=dt_gamma, image_width=RES)
+        torch.cuda.synchronize()
+    finally:
+        L.ngp_render_set_block_skip(1)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["stats"][:3], b["stats"][:3])
+
+
+@pytest.mark.parametrize("scene,pose", [("sring", 2), ("blobs", 4)])
+def test_fused_march_gives_every_ray_the_single_march_sample_count(full, oracle, dev, scene, pose):
+    """Constant density, constant step (dt_gamma 0), no saturation: a ray's weights_sum depends on its sample count alone
+    and strictly increases with it.  The counts come from march_rays_train (one march from near to far, bit-exact against
+    the oracle in test_gpu_raymarching.py): rays with equal counts must have bit-equal weights_sum, more samples more
+    weight -- i.e. the fused march (with block skipping) gave each of the 640,000 rays exactly that many samples."""
+    import raymarching
+    W = full["W"]
+    ren = _constant_density_renderer(dev, _scene_grid(W, oracle, scene), 1e-3)
+    o, d = W.get_rays(W.orbit_pose(pose), W.intrinsics(RES, RES), RES, RES)
+    o, d = t(o, dev), t(d, dev)
+    fused = ren.render_fused(o[None], d[None], bg_color=1, dt_gamma=0, image_width=RES)
+    nears, fars = raymarching.near_far_from_aabb(o, d, ren.aabb_infer, ren.min_near)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    _, _, _, rays = raymarching.march_rays_train(o, d, W.BOUND, ren.density_bitfield, ren.cascade, ren.grid_size, nears, fars, counter,
+                                                 -1, False, 128, True, 0.0, 1024)
+    n = rays[:, 2].long()
+    assert int(n.sum()) == int(fused["stats"][0]) and int(n.max()) < 1024
+    ws = fused["weights_sum"]
+    order = torch.argsort(n)
+    n_s, ws_s = n[order], ws[order]
+    same = n_s[1:] == n_s[:-1]
+    assert bool((ws_s[1:][same] == ws_s[:-1][same]).all()), "two rays with the same sample count differ in weights_sum"
+    assert bool((ws_s[1:][~same] > ws_s[:-1][~same]).all()), "weights_sum is not increasing with the sample count"
+    assert bool((ws[n == 0] == 0).all())

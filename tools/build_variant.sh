@@ -1,0 +1,15 @@
+# Build a variant of libngp_hip.so with extra -D flags for render_fused.hip: bash tools/build_variant.sh <name> [-DFOO=1 ...]
+# -> nerf-navigation_amd/lib/var/libngp_<name>.so (select it with NGP_HIP_LIB=...; tools/ab_variants.sh times several)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+name=$1; shift
+V=$ROOT/nerf-navigation_amd/lib/var
+mkdir -p $V
+cd $ROOT/nerf-navigation_amd/csrc
+make -s >/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-strict-aliasing -Wno-unused-function \
+    -DNGP_BUILD "$@" -c render_fused.hip -o $V/render_fused_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libngp_$name.so ../lib/obj/raymarching.o ../lib/obj/gridencoder.o \
+    ../lib/obj/shencoder.o ../lib/obj/ffmlp.o ../lib/obj/ffmlp_backward.o $V/render_fused_$name.o
+rm -f $V/render_fused_$name.o
+echo built $V/libngp_$name.so

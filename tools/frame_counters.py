@@ -1,0 +1,40 @@
+"""Packing / march statistics of one fused 800x800 frame (needs a -DRV_COUNTERS build for rounds and march trips):
+   NGP_HIP_LIB=.../libngp_counters.so python tools/frame_counters.py"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+importlib.import_module("nerf-navigation_amd")
+from ngp import workload as W  # noqa: E402
+from ngp.field import NGPFieldFF  # noqa: E402
+from ngp.render import NGPRenderer  # noqa: E402
+
+dev = torch.device("cuda:0")
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+model = W.make_model(0)
+field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(model)
+ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
+ren.load_density_grid(W.density_grid())
+o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(res, res), res, res)
+o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+out = ren.render_fused(o[None], d[None], bg_color=1, image_width=res, return_workspace=True)
+torch.cuda.synchronize()
+st = out["stats"].cpu().numpy().astype(np.int64)
+ws = out["workspace"][:128].view(torch.int32).cpu().numpy().astype(np.int64)
+print("samples", st[0], "rays with samples", st[2], "tiles", st[3], "fill %.3f" % (st[0] / (16.0 * max(st[3], 1))))
+if ws[1]:
+    print("wave rounds", ws[1], "march trips", ws[2], "tiles/round %.2f" % (st[3] / ws[1]), "trips/round %.2f" % (ws[2] / ws[1]),
+          "samples/round %.1f" % (st[0] / ws[1]))
+    print("lane probes: fine-tested", ws[3], "(of which samples", st[0], ") coarse-empty", ws[4], "super-empty", ws[5])
+
+    c = out["workspace"][32:88].view(torch.int64).cpu().numpy().view(np.uint64)
+    nw = 4096.0
+    cmin = float(np.uint64(0xFFFFFFFFFFFFFFFF) - c[6])
+    print("wave cycles (mean per wave, M): refill %.2f march %.2f tiles %.2f composite %.2f total %.2f | max %.2f min %.2f" % (
+        float(c[0]) / nw / 1e6, float(c[1]) / nw / 1e6, float(c[2]) / nw / 1e6, float(c[3]) / nw / 1e6, float(c[4]) / nw / 1e6,
+        float(c[5]) / 1e6, cmin / 1e6))

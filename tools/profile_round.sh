@@ -16,7 +16,9 @@ for set in \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
-  "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES SQ_INSTS_MFMA" ; do
+  "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES SQ_INSTS_MFMA" \
+  "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_IFETCH SQ_IFETCH_LEVEL" \
+  "GRBM_GUI_ACTIVE GRBM_COUNT TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" ; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu > $R/gpurun_out/${TAG}_pmc$i.log 2>&1
 done
