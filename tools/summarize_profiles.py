@@ -49,7 +49,7 @@ bj = os.path.join(src, f"{tag}_bench_under_profiler.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     bench = json.loads(open(bj).read())
 c = counters.get
-lines = [f"# {tag}: rocprofv3 summary for `k_render_frame` (bench.py, 800x800 S-ring, 1x MI355X)", ""]
+lines = [f"# {tag}: rocprofv3 summary for `k_render_frame_multi` (bench.py, 800x800 S-ring, 1x MI355X)", ""]
 lines.append(f"* kernel-trace --stats: **{avg_ms:.3f} ms** average over {stats[kname]['Calls']} launches "
              f"({float(stats[kname]['Percentage']):.2f} % of GPU time)")
 if bench:
