@@ -173,19 +173,29 @@ __global__ __launch_bounds__(256) void k_grid_forward(const float* __restrict__ 
 }
 
 // scatter: one lane per (sample, pair of features, level)   (reference: gridencoder.cu:227-314)
+//
+// Wave-aggregated when a lane carries all C features of its sample (C <= 2, the reference's hash grid): consecutive
+// samples of a ray sit in the same cell of a coarse level for dozens of steps, so the 64 lanes of a wave are a few runs of
+// lanes with the same cell and therefore the same 8 rows.  Each run is summed across its lanes in binary32 (segmented
+// shuffle scan: 6 steps) and its last lane issues ONE atomic per corner.  On the training workload that is 3x fewer
+// atomics overall and ~60x fewer on the coarsest levels, whose few thousand rows otherwise serialise in L2 (32 ms -> see
+// DESIGN.md).  Sums are at least as accurate as the reference's (it rounds every product to half and adds in half, in
+// arbitrary order, gridencoder.cu:302-308); the parity tests' tolerance is unchanged.
 template <typename T, uint32_t D, uint32_t C, uint32_t N_C>
 __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                        const int* __restrict__ offsets, T* __restrict__ grad_grid,
                                                        uint32_t B, uint32_t L, ge_levels lv, uint32_t gridtype, bool align_corners) {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     const uint32_t b = (uint32_t)(((uint64_t)tid * N_C) / C);
-    if (b >= B) return;
+    constexpr bool AGG = (C == N_C);                   // one lane = one sample: runs of lanes are runs of samples
+    if (!AGG && b >= B) return;
+    bool valid = b < B;
     const uint32_t level = blockIdx.y;
-    const uint32_t ch = tid * N_C - b * C;
+    const uint32_t ch = valid ? tid * N_C - b * C : 0u;
 
     T* gg = grad_grid + (uint64_t)(uint32_t)offsets[level] * C;
-    const float* in = inputs + (uint64_t)b * D;
-    const T* g = grad + ((uint64_t)level * B + b) * C + ch;
+    const float* in = inputs + (uint64_t)(valid ? b : 0u) * D;
+    const T* g = grad + ((uint64_t)level * B + (valid ? b : 0u)) * C + ch;
 
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const float scale = lv.scale[level];
@@ -196,14 +206,30 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
     #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         const float x = in[d];
-        if (x < 0 || x > 1) return;                   // out of range: contributes nothing
+        if (x < 0 || x > 1) {                          // out of range: contributes nothing
+            if (!AGG) return;
+            valid = false;
+        }
         pos[d] = x * scale + (align_corners ? 0.0f : 0.5f);
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
     }
     float gc[N_C];
     #pragma unroll
-    for (uint32_t c = 0; c < N_C; c++) gc[c] = (float)g[c];
+    for (uint32_t c = 0; c < N_C; c++) gc[c] = valid ? (float)g[c] : 0.0f;
+
+    // runs of consecutive lanes in the same cell
+    const int lane = (int)(threadIdx.x & 63u);
+    int start = lane;
+    bool tail = true;
+    if constexpr (AGG) {
+        bool same = valid && lane > 0 && __shfl_up((int)valid, 1, 64) != 0;
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) same = (__shfl_up(pg[d], 1, 64) == pg[d]) && same;
+        const unsigned long long heads = __ballot(!same);                      // bit l: lane l starts a run
+        start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));     // first lane of this lane's run
+        tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    }
 
     #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
@@ -214,17 +240,33 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
             if ((idx & (1u << d)) == 0) { wi *= 1 - pos[d]; pl[d] = pg[d]; }
             else { wi *= pos[d]; pl[d] = pg[d] + 1; }
         }
+        float v[N_C];
+        #pragma unroll
+        for (uint32_t c = 0; c < N_C; c++) v[c] = wi * gc[c];
+        if constexpr (AGG) {
+            #pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                float o[N_C];
+                #pragma unroll
+                for (uint32_t c = 0; c < N_C; c++) o[c] = __shfl_up(v[c], off, 64);
+                if (lane - off >= start) {
+                    #pragma unroll
+                    for (uint32_t c = 0; c < N_C; c++) v[c] += o[c];
+                }
+            }
+            if (!(tail && valid)) continue;
+        }
         const uint64_t row = (uint64_t)ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C + ch;
         if constexpr (sizeof(T) == 2) {
             static_assert(sizeof(T) != 2 || N_C == 2, "half scatter needs feature pairs");
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            h2 v;
-            v.x = (_Float16)(wi * gc[0]);             // (__half)(w * grad) : gridencoder.cu:302
-            v.y = (_Float16)(wi * gc[1]);
-            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gg + row), v);
+            h2 hv;
+            hv.x = (_Float16)v[0];                     // (__half)(w * grad) : gridencoder.cu:302
+            hv.y = (_Float16)v[1];
+            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gg + row), hv);
         } else {
             #pragma unroll
-            for (uint32_t c = 0; c < N_C; c++) unsafeAtomicAdd((float*)gg + row + c, wi * gc[c]);
+            for (uint32_t c = 0; c < N_C; c++) unsafeAtomicAdd((float*)gg + row + c, v[c]);
         }
     }
 }
