@@ -255,6 +255,10 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
                 }
             }
             if (!(tail && valid)) continue;
+            bool zero = true;                          // padding rows and samples behind a saturated ray carry exact zeros
+            #pragma unroll
+            for (uint32_t c = 0; c < N_C; c++) zero = zero && v[c] == 0.0f;
+            if (zero) continue;
         }
         const uint64_t row = (uint64_t)ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C + ch;
         if constexpr (sizeof(T) == 2) {
