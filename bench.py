@@ -100,11 +100,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # NGP_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- exercises the N > 1 code path on a one-GPU box (RCCL refuses two
+    # ranks on one device); timing lines from a rehearsal are not measurements
+    rehearsal = os.environ.get("NGP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     importlib.import_module("nerf-navigation_amd")
     from ngp import workload as W
