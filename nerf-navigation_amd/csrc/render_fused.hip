@@ -125,6 +125,9 @@ __device__ __forceinline__ rf_row2 rf_rows(const rf_params& P, uint32_t byte_off
 // Arithmetic identical, operation for operation, to k_grid_forward<_Float16,3,2> (gridencoder.hip); only the address
 // computation is arranged differently (byte offsets, strides folded into multiply-adds, the hash computed pre-shifted:
 // (y * p) << 2 == y * (p << 2) mod 2^32, and the power-of-two modulo taken on the operands: (a ^ b) & m == (a & m) ^ (b & m)).
+// INRANGE: the caller guarantees |w| <= bound (march samples are clamped to the box, raymarching.cu:365-367), so the
+// normalised position is in [0,1] and the out-of-range handling is dead code.
+template <bool INRANGE = false>
 __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
                                             float wx, float wy, float wz) {
     // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound).  When 2*bound is a power of two (every cascade-aligned
@@ -134,15 +137,22 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
     if (P.inv_b2 != 0.0f) { x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2; }
     else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
     // a sample outside [0,1]^3 encodes to zeros (gridencoder.cu:118-131); it gathers at the origin so that no load needs a guard
-    const bool oob = (x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1);
+    const bool oob = !INRANGE && ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
     if (oob) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; }
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;              // fast_hash primes (gridencoder.cu:35-51)
     uint32_t raw[4][8];
     float fx[4], fy[4], fz[4];
+    // positions of two levels at a time: packed binary32 multiply and add (same roundings as the scalar operations)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 ppx[2], ppy[2], ppz[2];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const f2 sc2 = {lv.scale[2 * h], lv.scale[2 * h + 1]};
+        ppx[h] = x0 * sc2 + 0.5f; ppy[h] = x1 * sc2 + 0.5f; ppz[h] = x2 * sc2 + 0.5f;
+    }
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float sc = lv.scale[i];
-        const float px = x0 * sc + 0.5f, py = x1 * sc + 0.5f, pz = x2 * sc + 0.5f;
+        const float px = ppx[i >> 1][i & 1], py = ppy[i >> 1][i & 1], pz = ppz[i >> 1][i & 1];
         const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
         const uint32_t gx = (uint32_t)flx, gy = (uint32_t)fly, gz = (uint32_t)flz;
         fx[i] = px - flx; fy[i] = py - fly; fz[i] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
@@ -573,6 +583,28 @@ __device__ __forceinline__ float rv_lattice_jump(float t, float dtc, float lim) 
     return j > 0.0f ? t1 + j * du : t1;                // j du < 2^(e-1) is a multiple of u: both operations exact
 }
 
+// The reference's step out of an empty cell (raymarching.cu:798-801): do { t += dt(t); } while (t < tt).  Returns the first
+// lattice point >= tt after at least one step, and in `prev` the lattice point before it.  With a constant step most of the
+// way is one exact multiply-add (rv_lattice_jump lands strictly below tt, or on the single step t + dt); the last steps
+// are real steps, so the result is the reference's bit for bit.
+__device__ __forceinline__ float rv_advance(const rv_consts& k, float t, float tt, float& prev) {
+    float tn;
+    int guard = 0;
+    if (k.dt_gamma == 0.0f) {
+        const float dtc = ngp_clampf(0.0f, k.dt_min, k.dt_max);
+        prev = t;
+        tn = rv_lattice_jump(t, dtc, tt);
+        while (tn < tt && ++guard < NGP_SKIP_GUARD) { prev = tn; tn += dtc; }
+    } else {
+        tn = t;
+        do {
+            prev = tn;
+            tn += ngp_clampf(tn * k.dt_gamma, k.dt_min, k.dt_max);
+        } while (tn < tt && ++guard < NGP_SKIP_GUARD);
+    }
+    return tn;
+}
+
 #ifndef RV_SKIP_WALK
 #define RV_SKIP_WALK 32
 #endif
@@ -640,21 +672,14 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
             q.at(m, ts);
             if (q.level == r.level && (q.nx >> sh) == (r.nx >> sh) && (q.ny >> sh) == (r.ny >> sh) && (q.nz >> sh) == (r.nz >> sh)) {
                 const float te = q.cell_exit(m, ts);
-                float ta = ts, tp;
-                do {
-                    tp = ta;
-                    ta += ngp_clampf(ta * m.dt_gamma, m.dt_min, m.dt_max);
-                } while (ta < te && ++guard < NGP_SKIP_GUARD);
-                if ((te - tp) > M && (ta - te) > M && guard < NGP_SKIP_GUARD) { t = ta; return false; }
+                float tp;
+                const float ta = rv_advance(m, ts, te, tp);
+                if ((te - tp) > M && (ta - te) > M) { t = ta; return false; }
             }
         }
     }
-    float tn = tc;
-    int guard = 0;
-    do {
-        tn += ngp_clampf(tn * m.dt_gamma, m.dt_min, m.dt_max);
-    } while (tn < tt && ++guard < NGP_SKIP_GUARD);
-    t = tn;
+    float tp;
+    t = rv_advance(m, tc, tt, tp);
     return false;
 }
 
@@ -681,7 +706,7 @@ __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_
     #pragma unroll
     for (int j = 0; j < 8; j++) x[j] = (_Float16)(px * (float)(j + 1) + py);
 #else
-    const ngp_h8 x = rf_encode(P, lv, cls, px, py, pz);
+    const ngp_h8 x = rf_encode<true>(P, lv, cls, px, py, pz);
 #endif
 #ifdef RV_EXPERIMENT_NOMLP         // timing-only build: no MLP
     sigma = 20.0f * fabsf((float)x[0] + (float)x[3]); cr = (float)x[1]; cg = (float)x[2]; cb = (float)shq[0];
