@@ -26,6 +26,11 @@
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 
+#ifndef RF_PAIR_LANES
+#define RF_PAIR_LANES 0                // 1: hashed levels: neighbouring lanes fetch the x-corner pair of one sample in one instruction
+#endif                                 // (half the L1 tag lookups, +64 VALU per tile).  A/B on MI355X: 5.2-5.4 ms with, 4.8-4.9 ms
+                                       // without: the texture path is busy per lane address (TA 70 %, TD 78 % busy), not per tag
+                                       // lookup, so merging lookups buys nothing and the DPP exchange costs VALU.  Off.
 #ifndef RF_MIX_BLEND
 #define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
 #endif
@@ -207,8 +212,33 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
                     off[c] = (dense ? id : ih) * 4u + lv.base4[i];
                 }
             }
-            #pragma unroll
-            for (int c = 0; c < 8; c++) raw[i][c] = rf_row(P, off[c]);
+#if RF_PAIR_LANES
+            if (cls.hashed & bit) {
+                // The two x-corners of a sample are rows idx and idx ^ (x ^ (x+1)): almost always the same 128-byte line, but
+                // two load instructions are two L1 tag lookups.  Lanes s and s^1 (neighbouring columns of the tile) therefore
+                // swap work: instruction A fetches both x-corners of the EVEN lane's sample (even lane: x, odd lane: x+1),
+                // instruction B both of the ODD lane's sample; the two addresses of an instruction sit in adjacent lanes and
+                // coalesce into one lookup, and a DPP exchange hands each lane its own sample's rows.  Same rows, same blend;
+                // half the lookups of the hashed levels for 8 extra VALU per (y, z) pair.
+                const bool odd = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 1u) != 0u;   // lane parity
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t o0 = off[2 * q], o1 = off[2 * q + 1];
+                    const uint32_t o1_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)o1, 0xA0, 0xf, 0xf, true);   // quad_perm [0,0,2,2]
+                    const uint32_t o0_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)o0, 0xF5, 0xf, 0xf, true);    // quad_perm [1,1,3,3]
+                    const uint32_t la = rf_row(P, odd ? o1_even : o0);
+                    const uint32_t lb = rf_row(P, odd ? o1 : o0_odd);
+                    const uint32_t lb_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)lb, 0xA0, 0xf, 0xf, true);
+                    const uint32_t la_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)la, 0xF5, 0xf, 0xf, true);
+                    raw[i][2 * q] = odd ? lb_even : la;
+                    raw[i][2 * q + 1] = odd ? lb : la_odd;
+                }
+            } else
+#endif
+            {
+                #pragma unroll
+                for (int c = 0; c < 8; c++) raw[i][c] = rf_row(P, off[c]);
+            }
         }
     }
     // Blend.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):

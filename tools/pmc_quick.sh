@@ -1,0 +1,20 @@
+#!/bin/bash
+# TCP / SQ counters of the fused frame kernel for one library variant:  bash tools/pmc_quick.sh <variant-name>
+set -u
+V=$1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp NGP_HIP_LIB=$R/nerf-navigation_amd/lib/var/libngp_$V.so
+cd /tmp
+rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_a -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu > $R/gpurun_out/q_${V}_a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_b -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu > $R/gpurun_out/q_${V}_b.log 2>&1
+python3 - <<PY
+import csv, glob, os, collections
+for tag in ("a", "b"):
+    fs = sorted(glob.glob("$R/gpurun_out/q_${V}_%s/*/*counter_collection.csv" % tag), key=os.path.getmtime)
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[-1])):
+        if "k_render_frame" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print("$V", k, "%.4g" % (sum(v) / len(v)))
+PY
