@@ -130,7 +130,8 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
 
 /* gridencoder.h:13 grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
  *                                       calc_grad_inputs, dy_dx, grad_inputs, gridtype, align_corners)
- * grad [L,B,C]; grad_embeddings [sO,C] PRE-ZEROED; grad_inputs [B,D] (all `dtype`). */
+ * grad [L,B,C]; grad_embeddings [sO,C] PRE-ZEROED, or NULL when only grad_inputs is wanted (frozen model: skips the
+ * scatter); grad_inputs [B,D] (all `dtype`). */
 int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                              void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,

@@ -356,8 +356,9 @@ static void ge_launch_backward(const void* grad, const float* inputs, const int*
                                const ge_levels& lv, bool calc, const void* dy_dx, void* gi, uint32_t gridtype, bool ac, hipStream_t s) {
     constexpr uint32_t N_C = C < 2 ? C : 2;           // features per lane (gridencoder.cu:380)
     const uint32_t nthreads = (uint32_t)(((uint64_t)B * C) / N_C);
-    hipLaunchKernelGGL((k_grid_backward<T, D, C, N_C>), dim3(ngp_div_up(nthreads, 256), L), dim3(256), 0, s,
-                       (const T*)grad, inputs, offsets, (T*)gg, B, L, lv, gridtype, ac);
+    if (gg)                                            // null: the caller does not need the table gradient (frozen model)
+        hipLaunchKernelGGL((k_grid_backward<T, D, C, N_C>), dim3(ngp_div_up(nthreads, 256), L), dim3(256), 0, s,
+                           (const T*)grad, inputs, offsets, (T*)gg, B, L, lv, gridtype, ac);
     if (calc)
         hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(ngp_div_up((uint64_t)B * D, 256)), dim3(256), 0, s,
                            (const T*)grad, (const T*)dy_dx, (T*)gi, B, L);
@@ -395,7 +396,8 @@ extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, c
                                         int align_corners, int dtype, void* stream) {
     (void)embeddings;                                  // kept for signature parity; the scatter never reads the table
     if (B == 0) return NGP_OK;
-    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
+    NGP_REQUIRE(grad && inputs && offsets, "grid_encode_backward: null pointer");
+    NGP_REQUIRE(grad_embeddings || calc_grad_inputs, "grid_encode_backward: nothing to compute (no table gradient, no input gradient)");
     NGP_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs), "grid_encode_backward: calc_grad_inputs needs dy_dx and grad_inputs");
     NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_backward: L must be in 1..32");
     NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_backward: dtype must be f32 or f16");

@@ -66,14 +66,20 @@ class _grid_encode(Function):
         calc_grad_inputs = ctx.calc_grad_inputs
 
         grad = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)
-        grad_embeddings = torch.zeros_like(embeddings)
+        # The reference always scatters into a dense zeros_like(embeddings) (grid.py:74).  A frozen model (the nav loop only
+        # differentiates w.r.t. poses: ngp/nav.py) does not need it: skip the 25-50 MB fill and the 128 atomics per sample.
+        need_table = ctx.needs_input_grad[1]
+        if not need_table and not calc_grad_inputs:
+            return None, None, None, None, None, None, None, None
+        grad_embeddings = torch.zeros_like(embeddings) if need_table else None
         if calc_grad_inputs:
             grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
         else:
             grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
 
         _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
-                                                       _hip.ptr(grad_embeddings), B, D, C, L, float(S), H, int(calc_grad_inputs),
+                                                       _hip.ptr(grad_embeddings) if need_table else None, B, D, C, L, float(S), H,
+                                                       int(calc_grad_inputs),
                                                        _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
                                                        _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")
 

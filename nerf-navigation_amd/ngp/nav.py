@@ -1,0 +1,81 @@
+"""The callers on the navigation side of the hot path (8f rows 3 and 4).
+
+  get_rays          nerf/utils.py:53-116 in torch on the device: full image, uniform random pixels, error-map sampling
+  NavQueries        the three lambdas simulate.py hands to the planner and the pose filter (simulate.py:340-347):
+                      density_fn(x)            = density(x.reshape(-1,3) @ rot)['sigma'].reshape(x.shape[:-1])
+                      render_fn(rays_o, rays_d) = render(..., staged=True, bg_color=1., perturb=False)
+                      get_rays_fn(pose)
+                    with ONE difference that changes no result: the model is frozen (requires_grad_(False)).  The nav loop
+                    differentiates w.r.t. body points and camera poses only (nav/quad_plot.py:237, nav/estimator_helpers.py:316);
+                    with trainable parameters autograd also builds the 50 MB table gradient (128 atomics per point) and
+                    the weight-gradient GEMMs on every call, which the reference pays and throws away.  Frozen, the encoder's
+                    backward skips the scatter (gridencoder/grid.py) and autograd skips the dW GEMMs.
+Everything runs in fp32 without autocast, as simulate.py does.
+"""
+import torch
+
+ROT = ((0., 0., 1.), (1., 0., 0.), (0., 1., 0.))           # simulate.py:340: NeRF camera looks along +z, Blender along -z
+
+
+def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, generator=None):
+    """nerf/utils.py:53-116.  poses [B,4,4] cam2world, intrinsics (fx, fy, cx, cy) -> dict(rays_o, rays_d [B,N,3], inds ...).
+    `generator` seeds the random branches (the reference uses the global torch RNG)."""
+    device = poses.device
+    B = poses.shape[0]
+    fx, fy, cx, cy = intrinsics
+    jj, ii = torch.meshgrid(torch.linspace(0, H - 1, H, device=device), torch.linspace(0, W - 1, W, device=device), indexing="ij")
+    i = ii.reshape(1, H * W).expand(B, H * W) + 0.5          # custom_meshgrid(...).t(): row-major over the image
+    j = jj.reshape(1, H * W).expand(B, H * W) + 0.5
+    results = {}
+    if N > 0:
+        N = min(N, H * W)
+        if error_map is None:
+            inds = torch.randint(0, H * W, size=[N], device=device, generator=generator).expand(B, N)       # may duplicate
+        else:
+            inds_coarse = torch.multinomial(error_map.to(device), N, replacement=False, generator=generator)   # [B,N] in [0, 128*128)
+            inds_x, inds_y = inds_coarse // 128, inds_coarse % 128
+            sx, sy = H / 128, W / 128
+            inds_x = (inds_x * sx + torch.rand(B, N, device=device, generator=generator) * sx).long().clamp(max=H - 1)
+            inds_y = (inds_y * sy + torch.rand(B, N, device=device, generator=generator) * sy).long().clamp(max=W - 1)
+            inds = inds_x * W + inds_y
+            results["inds_coarse"] = inds_coarse
+        i = torch.gather(i, -1, inds)
+        j = torch.gather(j, -1, inds)
+        results["inds"] = inds
+    zs = torch.ones_like(i)
+    xs = (i - cx) / fx * zs
+    ys = (j - cy) / fy * zs
+    directions = torch.stack((xs, ys, zs), dim=-1)
+    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+    results["rays_o"] = rays_o
+    results["rays_d"] = rays_d
+    return results
+
+
+class NavQueries:
+    """density_fn / render_fn / get_rays_fn for Planner and Estimator, bound to a frozen renderer."""
+
+    def __init__(self, renderer, intrinsics, H, W, num_steps=512, upsample_steps=0, max_ray_batch=4096, freeze=True):
+        self.renderer = renderer.eval()
+        if freeze:
+            for p in self.renderer.parameters():
+                p.requires_grad_(False)
+        self.intrinsics, self.H, self.W = intrinsics, H, W
+        self.render_kwargs = dict(num_steps=num_steps, upsample_steps=upsample_steps, max_ray_batch=max_ray_batch)
+        self._rot = None
+
+    def _rot_on(self, device):
+        if self._rot is None or self._rot.device != device:
+            self._rot = torch.tensor(ROT, device=device, dtype=torch.float32)
+        return self._rot
+
+    def density_fn(self, x):
+        return self.renderer.density(x.reshape(-1, 3) @ self._rot_on(x.device))["sigma"].reshape(x.shape[:-1])
+
+    def render_fn(self, rays_o, rays_d):
+        return self.renderer.render(rays_o, rays_d, staged=True, bg_color=1.0, perturb=False, **self.render_kwargs)
+
+    def get_rays_fn(self, pose):
+        return get_rays(pose, self.intrinsics, self.H, self.W)

@@ -38,6 +38,16 @@ def filt():
     out["image"].sum().backward()
 print("(iii) run() 1024 rays x 512 steps + backward: %.3f ms" % timeit(filt, 20))
 
+from ngp import nav
+q = nav.NavQueries(ren, W.intrinsics(32, 32), 32, 32)
+def planner_frozen():
+    p = pts.clone().requires_grad_(True)
+    q.density_fn(p).sum().backward()
+def filt_frozen():
+    ro, rd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    q.render_fn(ro, rd)["image"].sum().backward()
+print("frozen model: (ii) %.3f ms   (iii) %.3f ms" % (timeit(planner_frozen, 50), timeit(filt_frozen, 20)))
+filt = filt_frozen
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for _ in range(3):
