@@ -132,43 +132,43 @@ __device__ __forceinline__ rf_row2 rf_rows(const rf_params& P, uint32_t byte_off
 // (y * p) << 2 == y * (p << 2) mod 2^32, and the power-of-two modulo taken on the operands: (a ^ b) & m == (a & m) ^ (b & m)).
 // INRANGE: the caller guarantees |w| <= bound (march samples are clamped to the box, raymarching.cu:365-367), so the
 // normalised position is in [0,1] and the out-of-range handling is dead code.
-template <bool INRANGE = false>
-__device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
-                                            float wx, float wy, float wz) {
+// The gathers of one PAIR of iterations (h = 0: levels g and 4+g, h = 1: levels 8+g and 12+g) for a normalised position:
+// cell, fractions, byte offsets, loads issued (nothing waits here).  Splitting the encoder in pairs lets the frame kernel
+// issue the next tile's pair 1 (the hashed levels, the slow gathers) before the current tile's MLP (RV_PIPELINE).
+struct rf_pair { uint32_t raw[2][8]; float fx[2], fy[2], fz[2]; };
+
+__device__ __forceinline__ void rf_normalise(const rf_params& P, float wx, float wy, float wz, float& x0, float& x1, float& x2) {
     // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound).  When 2*bound is a power of two (every cascade-aligned
     // bound) the quotient equals the product with the exact reciprocal, bit for bit, and skips three IEEE divisions.
     const float b2 = 2 * P.bound;
-    float x0, x1, x2;
     if (P.inv_b2 != 0.0f) { x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2; }
     else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
-    // a sample outside [0,1]^3 encodes to zeros (gridencoder.cu:118-131); it gathers at the origin so that no load needs a guard
-    const bool oob = !INRANGE && ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
-    if (oob) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; }
+}
+
+template <int H>
+__device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
+                                               float x0, float x1, float x2, rf_pair& o) {
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;              // fast_hash primes (gridencoder.cu:35-51)
-    uint32_t raw[4][8];
-    float fx[4], fy[4], fz[4];
-    // positions of two levels at a time: packed binary32 multiply and add (same roundings as the scalar operations)
+    // positions of the two levels at once: packed binary32 multiply and add (same roundings as the scalar operations)
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 ppx[2], ppy[2], ppz[2];
+    const f2 sc2 = {lv.scale[2 * H], lv.scale[2 * H + 1]};
+    const f2 ppx = x0 * sc2 + 0.5f, ppy = x1 * sc2 + 0.5f, ppz = x2 * sc2 + 0.5f;
+    uint32_t (&raw)[2][8] = o.raw;
+    float (&fx)[2] = o.fx; float (&fy)[2] = o.fy; float (&fz)[2] = o.fz;
     #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const f2 sc2 = {lv.scale[2 * h], lv.scale[2 * h + 1]};
-        ppx[h] = x0 * sc2 + 0.5f; ppy[h] = x1 * sc2 + 0.5f; ppz[h] = x2 * sc2 + 0.5f;
-    }
-    #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float px = ppx[i >> 1][i & 1], py = ppy[i >> 1][i & 1], pz = ppz[i >> 1][i & 1];
+    for (int i = 2 * H; i < 2 * H + 2; i++) {
+        const float px = ppx[i & 1], py = ppy[i & 1], pz = ppz[i & 1];
         const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
         const uint32_t gx = (uint32_t)flx, gy = (uint32_t)fly, gz = (uint32_t)flz;
-        fx[i] = px - flx; fy[i] = py - fly; fz[i] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
+        fx[i & 1] = px - flx; fy[i & 1] = py - fly; fz[i & 1] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
         const uint32_t bit = 1u << i;
         if (cls.dense & bit) {
             // x + y*s1 + z*s2 (always < size); the x-neighbour is the next row: one 8-byte load per (y, z)
             const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + lv.base4[i]));
             const uint32_t o01 = o00 + lv.s1b[i], o10 = o00 + lv.s2b[i], o11 = o01 + lv.s2b[i];
             const rf_row2 r0 = rf_rows(P, o00), r1 = rf_rows(P, o01), r2 = rf_rows(P, o10), r3 = rf_rows(P, o11);
-            raw[i][0] = r0.lo; raw[i][1] = r0.hi; raw[i][2] = r1.lo; raw[i][3] = r1.hi;
-            raw[i][4] = r2.lo; raw[i][5] = r2.hi; raw[i][6] = r3.lo; raw[i][7] = r3.hi;
+            raw[i & 1][0] = r0.lo; raw[i & 1][1] = r0.hi; raw[i & 1][2] = r1.lo; raw[i & 1][3] = r1.hi;
+            raw[i & 1][4] = r2.lo; raw[i & 1][5] = r2.hi; raw[i & 1][6] = r3.lo; raw[i & 1][7] = r3.hi;
         } else {
             uint32_t off[8];                                           // byte offsets of the 8 corners
             if (cls.hashed & bit) {
@@ -230,49 +230,67 @@ __device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_le
                     const uint32_t lb = rf_row(P, odd ? o1 : o0_odd);
                     const uint32_t lb_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)lb, 0xA0, 0xf, 0xf, true);
                     const uint32_t la_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)la, 0xF5, 0xf, 0xf, true);
-                    raw[i][2 * q] = odd ? lb_even : la;
-                    raw[i][2 * q + 1] = odd ? lb : la_odd;
+                    raw[i & 1][2 * q] = odd ? lb_even : la;
+                    raw[i & 1][2 * q + 1] = odd ? lb : la_odd;
                 }
             } else
 #endif
             {
                 #pragma unroll
-                for (int c = 0; c < 8; c++) raw[i][c] = rf_row(P, off[c]);
+                for (int c = 0; c < 8; c++) raw[i & 1][c] = rf_row(P, off[c]);
             }
         }
     }
-    // Blend.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):
-    //   w = (wx * wy) * wz in binary32;  results[ch] += w * grid[...]  ==  half(float(result) + float(half(w * float(v))))
-    // RF_MIX_BLEND: v_fma_mixlo/mixhi_f16 compute half(fma32(w, float(v), +0)) in one instruction per feature -- the same
-    // two roundings (binary32 product, then binary16) as the cvt / mul / cvt sequence; the +0 addend only turns a -0 product
-    // into +0, which a sum that starts at +0 cannot tell apart.  The packed-half add is the correctly rounded binary16 sum.
+}
+
+// Blend of one level.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):
+//   w = (wx * wy) * wz in binary32;  results[ch] += w * grid[...]  ==  half(float(result) + float(half(w * float(v))))
+// RF_MIX_BLEND: v_fma_mixlo/mixhi_f16 compute half(fma32(w, float(v), +0)) in one instruction per feature -- the same
+// two roundings (binary32 product, then binary16) as the cvt / mul / cvt sequence; the +0 addend only turns a -0 product
+// into +0, which a sum that starts at +0 cannot tell apart.  The packed-half add is the correctly rounded binary16 sum.
+__device__ __forceinline__ void rf_blend_pair(const rf_pair& in, int h, ngp_h8& out) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    ngp_h8 out;
     #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const f2 wx = {1 - fx[i], fx[i]};
-        const float wy0 = 1 - fy[i], wz0 = 1 - fz[i];
-        const f2 wxy0 = wx * wy0, wxy1 = wx * fy[i];
-        const f2 w[4] = {wxy0 * wz0, wxy1 * wz0, wxy0 * fz[i], wxy1 * fz[i]};     // (y, z) = (0,0) (1,0) (0,1) (1,1)
+    for (int j = 0; j < 2; j++) {
+        const f2 wx = {1 - in.fx[j], in.fx[j]};
+        const float wy0 = 1 - in.fy[j], wz0 = 1 - in.fz[j];
+        const f2 wxy0 = wx * wy0, wxy1 = wx * in.fy[j];
+        const f2 w[4] = {wxy0 * wz0, wxy1 * wz0, wxy0 * in.fz[j], wxy1 * in.fz[j]};   // (y, z) = (0,0) (1,0) (0,1) (1,1)
         h2 acc = {(_Float16)0.0f, (_Float16)0.0f};
         #pragma unroll
         for (int c = 0; c < 8; c++) {
             const float wc = w[c >> 1][c & 1];
 #if RF_MIX_BLEND
             uint32_t prod;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(prod) : "v"(wc), "v"(raw[i][c]));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(prod) : "v"(wc), "v"(raw[i][c]));
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(prod) : "v"(wc), "v"(in.raw[j][c]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(prod) : "v"(wc), "v"(in.raw[j][c]));
             acc = acc + __builtin_bit_cast(h2, prod);
 #else
-            const h2 v = __builtin_bit_cast(h2, raw[i][c]);
+            const h2 v = __builtin_bit_cast(h2, in.raw[j][c]);
             const h2 prod = {(_Float16)(wc * (float)v.x), (_Float16)(wc * (float)v.y)};
             acc = acc + prod;
 #endif
         }
-        out[2 * i] = acc.x;
-        out[2 * i + 1] = acc.y;
+        out[4 * h + 2 * j] = acc.x;
+        out[4 * h + 2 * j + 1] = acc.y;
     }
+}
+
+template <bool INRANGE = false>
+__device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
+                                            float wx, float wy, float wz) {
+    float x0, x1, x2;
+    rf_normalise(P, wx, wy, wz, x0, x1, x2);
+    // a sample outside [0,1]^3 encodes to zeros (gridencoder.cu:118-131); it gathers at the origin so that no load needs a guard
+    const bool oob = !INRANGE && ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
+    if (oob) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; }
+    rf_pair a, b;
+    rf_gather_pair<0>(P, lv, cls, x0, x1, x2, a);
+    rf_gather_pair<1>(P, lv, cls, x0, x1, x2, b);
+    ngp_h8 out;
+    rf_blend_pair(a, 0, out);
+    rf_blend_pair(b, 1, out);
     if (oob) {
         #pragma unroll
         for (int j = 0; j < 8; j++) out[j] = (_Float16)0.0f;
@@ -472,6 +490,11 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
 #endif                                        // RV_S = 4 (80 KiB) only fit beside ONE copy of the weights per CU
+#ifndef RV_PIPELINE
+#define RV_PIPELINE 0                  // 1: issue the next tile's hashed-level gathers before the current tile's MLP (software
+#endif                                 // pipeline across tiles).  A/B on MI355X: 5.0-5.2 ms with, 4.8-5.0 ms without: four waves per
+                                       // SIMD already overlap gather and MLP phases; the texture path is throughput-, not latency-
+                                       // bound, and the tile list / extra shuffles cost VALU.  Off.
 #ifndef RV_TILE_ORDER
 #define RV_TILE_ORDER 0                // 1: hand out the 8x8 pixel tiles most expensive first (k_tile_estimate / k_tile_order).
 #endif                                 // A/B on MI355X: 5.25-5.35 ms with, 5.0-5.2 ms without: the frame is bound by L1 tag and
@@ -726,22 +749,21 @@ __device__ __forceinline__ float rv_skip_margin(const rv_ray& r, float bound, fl
 
 __device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int f, int lane) { return lds_w[f * 64 + lane]; }
 
+__device__ __forceinline__ void rv_mlp_tile(const ngp_h8* __restrict__ lds_w, int lane, const ngp_h8 x, ngp_h4 shq,
+                                            float& sigma, float& cr, float& cg, float& cb);
+
 // rf_field_tile with the weights streamed from LDS and the SH coefficients of the column's ray read from LDS
 __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
                                               const ngp_h8* __restrict__ lds_w, int lane,
                                               float px, float py, float pz, ngp_h4 shq,
                                               float& sigma, float& cr, float& cg, float& cb) {
-#ifdef RV_EXPERIMENT_NOENCODE      // timing-only build: no hash-grid encoding
-    ngp_h8 x;
-    #pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = (_Float16)(px * (float)(j + 1) + py);
-#else
     const ngp_h8 x = rf_encode<true>(P, lv, cls, px, py, pz);
-#endif
-#ifdef RV_EXPERIMENT_NOMLP         // timing-only build: no MLP
-    sigma = 20.0f * fabsf((float)x[0] + (float)x[3]); cr = (float)x[1]; cg = (float)x[2]; cb = (float)shq[0];
-    return;
-#endif
+    rv_mlp_tile(lds_w, lane, x, shq, sigma, cr, cg, cb);
+}
+
+// The two networks on one 16-column tile whose encoded features are already in B-fragment layout (weights from LDS).
+__device__ __forceinline__ void rv_mlp_tile(const ngp_h8* __restrict__ lds_w, int lane, const ngp_h8 x, ngp_h4 shq,
+                                            float& sigma, float& cr, float& cg, float& cb) {
     const ngp_f4 zero = {0.f, 0.f, 0.f, 0.f};
     ngp_h8 act[2];
     {
@@ -1208,6 +1230,59 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
 
         RV_TICK(c_march)
         // ---- field evaluation: for each group of 16 rays, tile k = their k-th samples ----
+#if RV_PIPELINE
+        {
+            // Software pipeline across tiles: the gathers of the hashed half of the NEXT tile (levels 8+g, 12+g: the slow
+            // ones) are issued before the MLP of the current tile, so a wave keeps the texture path busy while it sits in
+            // its 36-MFMA chain.  Costs 25 registers across the MLP (16 rows, 6 fractions, the next position).
+            unsigned long long list = 0ull;            // the round's tiles, 4 bits each: (p << 2) | k
+            int T = 0;
+            #pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int cc = __shfl(cnt, 16 * p + s, 64);
+                #pragma unroll
+                for (int k = 0; k < RV_S; k++)
+                    if (__ballot(cc > k) != 0ull) { list |= (unsigned long long)(p * 4 + k) << (4 * T); T++; }
+            }
+            const rf_lane_levels lv = lds_lv[g];
+            rf_pair nxt;
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;        // normalised position of the tile whose pair 1 is in flight
+            if (T > 0) {
+                const int code = (int)(list & 15ull), src = 16 * (code >> 2) + s, k = code & 3;
+                float4 q = wave_smp[src * RV_S + k];
+                if (!(__shfl(cnt, src, 64) > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
+                rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nxt);
+            }
+            #pragma unroll 1
+            for (int n = 0; n < T; n++) {
+                const int code = (int)((list >> (4 * n)) & 15ull), src = 16 * (code >> 2) + s, k = code & 3;
+                const bool valid = __shfl(cnt, src, 64) > k;
+                const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
+                n_tiles++;
+                rf_pair cur;
+                rf_gather_pair<0>(P, lv, cls, x0, x1, x2, cur);
+                ngp_h8 x;
+                rf_blend_pair(cur, 0, x);
+                rf_blend_pair(nxt, 1, x);
+                if (n + 1 < T) {
+                    const int code1 = (int)((list >> (4 * (n + 1))) & 15ull), src1 = 16 * (code1 >> 2) + s, k1 = code1 & 3;
+                    float4 q = wave_smp[src1 * RV_S + k1];
+                    if (!(__shfl(cnt, src1, 64) > k1)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
+                    rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // the prefetch stays above the MLP
+                float a, b, c, d;
+                rv_mlp_tile(lds_w, lane, x, shq, a, b, c, d);
+                if (g == 0 && valid) {                   // the half-precision network outputs replace (x, y) of the slot
+                    ngp_h4 r;
+                    r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
+                    *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k]) = r;
+                }
+            }
+        }
+#else
         #pragma unroll 1
         for (int p = 0; p < 4; p++) {
             const int src = 16 * p + s;
@@ -1230,6 +1305,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 }
             }
         }
+#endif
 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
