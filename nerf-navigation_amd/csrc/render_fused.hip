@@ -37,8 +37,10 @@
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
 #ifndef RF_PROBES_PER_ROUND
-#define RF_PROBES_PER_ROUND 32         // A/B on MI355X (800x800 S-ring): 4: 26.0 ms, 8: 19.9, 16: 12.5, 32: 12.2, 48: 12.6
-#endif
+#define RF_PROBES_PER_ROUND 128        // march iterations a round may spend so that every lane can collect its RV_S samples.
+#endif                                 // A/B on MI355X, ms per frame.  Before block skipping (each probe = one cell): 4: 26.0,
+                                       // 8: 19.9, 16: 12.5, 32: 12.2, 48: 12.6.  With block skipping and RV_S = 4: 6: 6.62, 10: 5.82,
+                                       // 16: 5.26, 24: 4.98, 32: 4.83, 48: 4.60, 64: 4.5-4.8, 128: 4.40, 256: 4.41, 1024: 4.58
 
 struct rf_params {
     const uint32_t* table;            // [sO] half2 rows
@@ -97,17 +99,19 @@ __device__ __forceinline__ void rf_setup_levels(const rf_params& P, int g, rf_la
 }
 
 // Which kind of code each iteration needs, decided once per kernel by the whole wave (bit i = iteration i).
-struct rf_iter_class { uint32_t dense, hashed, select; };
+struct rf_iter_class { uint32_t dense, hashed, select, reuse; };   // reuse: the cell (x,y,z) of every level packs into 3 x 10 bits
 
 __device__ __forceinline__ rf_iter_class rf_classify(const rf_lane_levels& lv) {   // call with all 64 lanes active
-    rf_iter_class c = {0u, 0u, 0u};
+    rf_iter_class c = {0u, 0u, 0u, 0u};
     #pragma unroll
     for (int i = 0; i < 4; i++) {
         const unsigned long long bd = __ballot(lv.s1b[i] != 0u), bh = __ballot(lv.mask4[i] != 0u);
         if (bd == ~0ull) c.dense |= 1u << i;                       // every lane: dense level
         else if (bh == ~0ull) c.hashed |= 1u << i;                 // every lane: hashed level with 2^k rows
         else if ((bd | bh) == ~0ull) c.select |= 1u << i;          // a mix of those two
-    }                                                              // otherwise (a hashed level whose size is not 2^k): generic
+                                                                   // otherwise (a hashed level whose size is not 2^k): generic
+        if (__ballot(lv.scale[i] <= 1021.0f) == ~0ull) c.reuse |= 1u << i;   // cell index <= scale + 1.5 < 1024 on every axis
+    }
     return c;
 }
 
@@ -145,9 +149,13 @@ __device__ __forceinline__ void rf_normalise(const rf_params& P, float wx, float
     else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
 }
 
-template <int H>
+// REUSE (frame kernel): consecutive tiles of a lane group hold consecutive samples of the same 16 rays, 3.4 mm apart, and on
+// all but the finest levels a ray stays in one cell for several samples.  `o` then still holds that cell's 8 rows from the
+// previous tile: a lane whose cell (packed in `key`) has not changed skips its loads (and, when the whole wave skips, the
+// address arithmetic).  Same rows, same blend; about 40 % fewer gather lanes on the benchmark frame.
+template <int H, bool REUSE = false>
 __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
-                                               float x0, float x1, float x2, rf_pair& o) {
+                                               float x0, float x1, float x2, rf_pair& o, uint32_t* key = nullptr) {
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;              // fast_hash primes (gridencoder.cu:35-51)
     // positions of the two levels at once: packed binary32 multiply and add (same roundings as the scalar operations)
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -162,6 +170,12 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
         const uint32_t gx = (uint32_t)flx, gy = (uint32_t)fly, gz = (uint32_t)flz;
         fx[i & 1] = px - flx; fy[i & 1] = py - fly; fz[i & 1] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
         const uint32_t bit = 1u << i;
+        if (REUSE && (cls.reuse & bit)) {
+            const uint32_t cell = gx | (gy << 10) | (gz << 20);
+            const bool same = cell == key[i];
+            key[i] = cell;
+            if (same) continue;
+        }
         if (cls.dense & bit) {
             // x + y*s1 + z*s2 (always < size); the x-neighbour is the next row: one 8-byte load per (y, z)
             const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + lv.base4[i]));
@@ -490,6 +504,10 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
 #endif                                        // RV_S = 4 (80 KiB) only fit beside ONE copy of the weights per CU
+#ifndef RV_REUSE_ROWS
+#define RV_REUSE_ROWS 0                // 1: a lane keeps the 8 rows of a level while its ray stays in the same cell (rf_gather_pair).
+#endif                                 // A/B on MI355X: L1 accesses -23 %, TA busy -8 %, VALU +8 % (cell keys, exec masks), frame
+                                       // time 4.95-5.06 vs 4.85 ms: the frame does not respond to memory-side savings.  Off.
 #ifndef RV_PIPELINE
 #define RV_PIPELINE 0                  // 1: issue the next tile's hashed-level gathers before the current tile's MLP (software
 #endif                                 // pipeline across tiles).  A/B on MI355X: 5.0-5.2 ms with, 4.8-5.0 ms without: four waves per
@@ -1102,7 +1120,7 @@ template <bool FIXED>
 __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame& F, const rf_iter_class cls_rt,
                                               const ngp_h8* __restrict__ lds_w, _Float16* lds_sh, const rf_lane_levels* lds_lv,
                                               float4* lds_smp, float* lds_d1, const uint32_t* lds_coarse) {
-    const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
+    const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u, 7u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the same, known to be uniform
 
@@ -1290,6 +1308,10 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             if (__ballot(ccol > 0) == 0ull) continue;
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             const rf_lane_levels lv = lds_lv[g];
+#if RV_REUSE_ROWS
+            rf_pair pa, pb;                            // the rows of the previous tile (same rays, previous sample)
+            uint32_t key[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#endif
             #pragma unroll 1
             for (int k = 0; k < RV_S; k++) {
                 if (__ballot(ccol > k) == 0ull) break;   // counts only shrink with k
@@ -1297,7 +1319,20 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 if (!(ccol > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);   // column without a k-th sample: harmless dummy
                 n_tiles++;
                 float a, b, c, d;
+#if RV_REUSE_ROWS
+                {
+                    float x0, x1, x2;
+                    rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
+                    rf_gather_pair<0, true>(P, lv, cls, x0, x1, x2, pa, key);
+                    rf_gather_pair<1, true>(P, lv, cls, x0, x1, x2, pb, key);
+                    ngp_h8 x;
+                    rf_blend_pair(pa, 0, x);
+                    rf_blend_pair(pb, 1, x);
+                    rv_mlp_tile(lds_w, lane, x, shq, a, b, c, d);
+                }
+#else
                 rv_field_tile(P, lv, cls, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
+#endif
                 if (g == 0 && ccol > k) {                // the half-precision network outputs replace (x, y) of the slot
                     ngp_h4 r;
                     r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
@@ -1394,7 +1429,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     }
     __syncthreads();
     const rf_iter_class cls = rf_classify(lds_lv[g]);
-    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u)
+    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u && cls.reuse == 7u)
         rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
     else
         rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
