@@ -151,6 +151,15 @@ int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
 int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, void* stream);
 
+/* ---- freqencoder (optional module: encoding.get_encoder('frequency'), encoding.py:56-58) ----------------------------- */
+/* freqencoder.h:7 freq_encode_forward(inputs, B, D, deg, C, outputs): inputs [B,D] f32 -> outputs [B,C] f32,
+ * C = D + 2*D*deg: [x | sin(2^f x), sin(2^f x + pi/2) for f < deg]. */
+int ngp_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream);
+/* freqencoder.h:10 freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs): grad, outputs [B,C] -> grad_inputs [B,D]
+ * (fully written). */
+int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                             float* grad_inputs, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* _ffmlp  (reference: ffmlp/src/ffmlp.h:8-14)                                */
 /* ------------------------------------------------------------------------ */

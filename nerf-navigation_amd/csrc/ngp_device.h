@@ -63,6 +63,28 @@ __device__ __forceinline__ float ngp_expf(float x) {
     return __int_as_float(__float_as_int(p) + (((int)n) << 23));
 }
 
+// Deterministic sine standing in for the reference's __sinf (freqencoder.cu:57), identical, operation for operation, to
+// o_sinf() of the oracle: octant reduction with a three-part pi/4 (Cody-Waite), then the degree-7 sine or degree-8 cosine
+// minimax polynomial on [-pi/4, pi/4]; plain multiplies and adds (the build never contracts them).  |x| < 8192.
+__device__ __forceinline__ float ngp_sinf(float x) {
+    float ax = __builtin_fabsf(x);
+    const bool neg = x < 0.0f;
+    float y = __builtin_floorf(ax * 1.27323954473516f);          // 4 / pi
+    int j = (int)y;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    bool flip = neg;
+    if (j > 3) { flip = !flip; j -= 4; }
+    const float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float z = r * r;
+    float v;
+    if (j == 1 || j == 2)
+        v = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    else
+        v = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    return flip ? -v : v;
+}
+
 // 10-bit-per-axis Morton interleave (reference: raymarching.cu:58-83)
 __device__ __forceinline__ uint32_t ngp_spread3(uint32_t v) {
     v = (v * 0x00010001u) & 0xFF0000FFu;

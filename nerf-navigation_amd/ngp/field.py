@@ -45,14 +45,17 @@ def get_encoder(encoding, input_dim=3, degree=4, num_levels=16, level_dim=2, bas
     """encoding.py:45-77 for the encoders on the hot path."""
     if encoding == "None":
         return (lambda x, **kw: x), input_dim
-    if encoding == "sphere_harmonics":
+    if encoding == "frequency":
+        from freqencoder import FreqEncoder
+        enc = FreqEncoder(input_dim=input_dim, degree=kwargs.get("multires", 6))
+    elif encoding == "sphere_harmonics":
         enc = SHEncoder(input_dim=input_dim, degree=degree)
     elif encoding in ("hashgrid", "tiledgrid"):
         enc = GridEncoder(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim, base_resolution=base_resolution,
                           log2_hashmap_size=log2_hashmap_size, desired_resolution=desired_resolution,
                           gridtype="hash" if encoding == "hashgrid" else "tiled", align_corners=align_corners)
     else:
-        raise NotImplementedError("Unknown encoding mode, choose from [None, sphere_harmonics, hashgrid, tiledgrid]")
+        raise NotImplementedError("Unknown encoding mode, choose from [None, frequency, sphere_harmonics, hashgrid, tiledgrid]")
     return enc, enc.output_dim
 
 

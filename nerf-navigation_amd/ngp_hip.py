@@ -44,6 +44,8 @@ _SIGNATURES = {
                                          c_vp, c_vp, c_u32, c_int, c_int, c_vp]),
     "ngp_sh_encode_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_int, c_vp, c_vp]),
     "ngp_sh_encode_backward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_freq_encode_forward": (c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp]),
+    "ngp_freq_encode_backward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp]),
     "ngp_ffmlp_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_ffmlp_inference": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_ffmlp_backward_workspace": (c_sz, [c_u32, c_u32, c_u32, c_u32]),

@@ -897,4 +897,63 @@ O_API void o_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const 
     free(gw); free(wf);
 }
 
+/* ------------------------------------------------------------------ */
+/* freqencoder (freqencoder/src/freqencoder.cu:27-92)                  */
+/* ------------------------------------------------------------------ */
+
+/* Deterministic stand-in for __sinf (freqencoder.cu:57), the same operations as ngp_sinf() of the HIP library: octant
+ * reduction with a three-part pi/4, degree-7 sine / degree-8 cosine polynomial on [-pi/4, pi/4]. */
+static inline float o_sinf(float x) {
+    float ax = fabsf(x);
+    const int neg = x < 0.0f;
+    float y = floorf(ax * 1.27323954473516f);
+    int j = (int)y;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    int flip = neg;
+    if (j > 3) { flip = !flip; j -= 4; }
+    const float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float z = r * r;
+    float v;
+    if (j == 1 || j == 2)
+        v = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    else
+        v = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    return flip ? -v : v;
+}
+
+O_API void o_sinf_array(const float* x, float* y, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) y[i] = o_sinf(x[i]);
+}
+
+/* kernel_freq (freqencoder.cu:27-60): outputs [B,C], C = D + 2 D deg */
+O_API void o_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs) {
+    (void)deg;
+    for (uint64_t t = 0; t < (uint64_t)B * C; t++) {
+        const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t - (uint64_t)b * C);
+        const float* in = inputs + (uint64_t)b * D;
+        if (c < D) { outputs[t] = in[c]; continue; }
+        const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
+        const float phase_shift = (float)(col % 2) * (3.141592653589793f / 2);
+        outputs[t] = o_sinf(scalbnf(in[d], (int)freq) + phase_shift);
+    }
+}
+
+/* kernel_freq_backward (freqencoder.cu:65-92) */
+O_API void o_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                                  float* grad_inputs) {
+    for (uint64_t t = 0; t < (uint64_t)B * D; t++) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (uint64_t)b * D);
+        const float* g = grad + (uint64_t)b * C;
+        const float* o = outputs + (uint64_t)b * C;
+        float result = g[d];
+        g += D; o += D;
+        for (uint32_t f = 0; f < deg; f++) {
+            result += scalbnf(1.0f, (int)f) * (g[d] * o[D + d] - g[D + d] * o[d]);
+            g += 2 * D; o += 2 * D;
+        }
+        grad_inputs[t] = result;
+    }
+}
+
 O_API int o_abi_version(void) { return 1; }

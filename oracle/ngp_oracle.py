@@ -64,6 +64,32 @@ def expf(x):
     return y
 
 
+def sinf(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().o_sinf_array(_p(x), _p(y), c_u32(x.size))
+    return y
+
+
+def freq_encode_forward(inputs, degree):
+    """freqencoder.cu:27-60.  inputs [B,D] f32 -> [B, D + 2 D degree] f32."""
+    x = _f32(inputs)
+    B, D = x.shape
+    C = D + 2 * D * degree
+    out = np.empty((B, C), np.float32)
+    lib().o_freq_encode_forward(_p(x), c_u32(B), c_u32(D), c_u32(degree), c_u32(C), _p(out))
+    return out
+
+
+def freq_encode_backward(grad, outputs, input_dim, degree):
+    """freqencoder.cu:65-92.  grad, outputs [B,C] -> grad_inputs [B,D]."""
+    g, o = _f32(grad), _f32(outputs)
+    B, C = g.shape
+    gi = np.empty((B, input_dim), np.float32)
+    lib().o_freq_encode_backward(_p(g), _p(o), c_u32(B), c_u32(input_dim), c_u32(degree), c_u32(C), _p(gi))
+    return gi
+
+
 def f32_to_f16_bits(x):
     x = _f32(x)
     y = np.empty(x.shape, dtype=np.uint16)

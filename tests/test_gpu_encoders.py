@@ -170,3 +170,35 @@ def test_sh_encoder_forward_backward(dev, degree):
     # no gradient requested => backward returns None and dy_dx is never materialised
     y2 = enc(t(v, dev))
     assert not y2.requires_grad
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# freqencoder (optional fifth module)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,degree", [(3, 6), (3, 4), (2, 10), (5, 1)])
+def test_freq_encoder_bit_exact_and_gradient(oracle, dev, D, degree):
+    from freqencoder import FreqEncoder, freq_encode
+    rng = np.random.default_rng(D * 100 + degree)
+    x = rng.uniform(-2, 2, size=(3001, D)).astype(np.float32)
+    x[:3] = 0.0
+    enc = FreqEncoder(input_dim=D, degree=degree)
+    assert enc.output_dim == D + 2 * D * degree
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    y = enc(xt)
+    ref = oracle.freq_encode_forward(x, degree)
+    assert y.shape == ref.shape and np.array_equal(y.detach().cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    y.backward(torch.from_numpy(g).to(dev))
+    dref = oracle.freq_encode_backward(g, ref, D, degree)
+    assert np.array_equal(xt.grad.cpu().numpy().view(np.uint32), dref.view(np.uint32))
+    # prefix shapes, autocast (inputs are cast to float32), empty batch
+    with torch.autocast("cuda", dtype=torch.float16):
+        y3 = enc(torch.from_numpy(x[:12]).to(dev).half().view(3, 4, D))
+    assert y3.shape == (3, 4, enc.output_dim) and y3.dtype == torch.float32
+    assert freq_encode(torch.zeros(0, D, device=dev), degree, enc.output_dim).shape == (0, enc.output_dim)
+
+
+def test_get_encoder_frequency(dev):
+    from ngp.field import get_encoder
+    enc, dim = get_encoder("frequency", input_dim=3, multires=6)
+    assert dim == 39 and enc(torch.zeros(5, 3, device=dev)).shape == (5, 39)

@@ -208,3 +208,34 @@ def test_trunc_exp_golden_from_reference_activation(oracle):
     # the deterministic exp the fused kernel uses for trunc_exp's forward agrees with it to 2 ulp over its range
     m = (x > -87) & (x < 88)
     assert np.max(np.abs(oracle.expf(x[m]) - y[m]) / y[m]) < 2.5e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# freqencoder (the optional fifth module): oracle vs the reference's own pure-torch FreqEncoder and vs float64
+# ---------------------------------------------------------------------------------------------------------------------
+def test_sinf_stand_in_accuracy(oracle):
+    x = np.concatenate([np.linspace(-70, 70, 200001), np.random.default_rng(0).uniform(-8192, 8192, 100000)]).astype(np.float32)
+    y = oracle.sinf(x)
+    ref = np.sin(x.astype(np.float64))
+    assert np.max(np.abs(y - ref)[np.abs(x) <= 70]) < 1.3e-7                         # about one ulp of 1.0
+    assert np.max(np.abs(y - ref)) < 2e-4                                            # three-part reduction degrades slowly
+    assert oracle.sinf(np.float32([0.0]))[0] == 0.0 and oracle.sinf(np.float32([-0.0]))[0] == 0.0
+
+
+def test_freq_encoder_matches_the_reference_torch_class(oracle):
+    """tests/golden/freq_encoder.npz was produced by the reference's encoding.FreqEncoder (pure torch) and torch autograd."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "freq_encoder.npz"))
+    deg = int(z["degree"])
+    y = oracle.freq_encode_forward(z["x"], deg)
+    assert y.shape == z["y"].shape == (z["x"].shape[0], 3 + 6 * deg)
+    assert np.array_equal(y[:, :3], z["x"])                                          # the input copy is exact
+    # torch: sin / cos of (x * 2^f) in float32 libm; ours: sin(ldexp(x, f) + phase) with the deterministic sinf.  The cosine
+    # column adds a float32 pi/2 to the argument, which costs up to half an ulp of the argument (|arg| <= 64 + 1.6).
+    assert np.max(np.abs(y - z["y"])) < 5e-6
+    dx = oracle.freq_encode_backward(z["g"], y, 3, deg)
+    assert np.max(np.abs(dx - z["dx"])) < 2e-3 * np.max(np.abs(z["dx"]))              # sums of 2^f-weighted terms, f up to 5
+    # and against float64 directly
+    xs = z["x"].astype(np.float64)
+    want = np.concatenate([xs] + [fn(xs * 2.0 ** f) for f in range(deg) for fn in (np.sin, np.cos)], axis=1)
+    assert np.max(np.abs(y - want)) < 5e-6
