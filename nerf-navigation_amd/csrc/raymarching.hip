@@ -14,6 +14,7 @@ extern "C" int ngp_abi_version(void) { return 1; }
 extern "C" const char* ngp_last_error(void) { return ngp_err_buf; }
 
 static constexpr uint32_t RM_BLOCK = 256;
+static constexpr uint32_t RM_CHUNK = 8;         // samples fetched ahead by the per-ray composite loops
 
 // ---------------------------------------------------------------------------
 // near / far
@@ -323,16 +324,30 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_train_fwd(const float* _
     const float* c = rgbs + 3ull * offset;
     const float* dl = deltas + 2ull * offset;
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
-    for (uint32_t k = 0; k < num_steps; k++) {
-        const float alpha = 1.0f - ngp_expf(-s[0] * dl[0]);
-        const float w = alpha * T;
-        r += w * c[0]; g += w * c[1]; b += w * c[2];
-        t += dl[1];
-        d += w * t;
-        ws += w;
-        T *= 1.0f - alpha;
-        if (T < 1e-4f) break;
-        s++; c += 3; dl += 2;
+    // One ray per lane and only a few thousand rays per step: the loop is bound by the latency of its six loads per sample.
+    // Samples are therefore fetched RM_CHUNK at a time (all loads of a chunk in flight together) and then composited in the
+    // reference's order with the reference's arithmetic: same results, a fraction of the exposed latency.
+    bool done = false;
+    for (uint32_t k0 = 0; k0 < num_steps && !done; k0 += RM_CHUNK) {
+        float sv[RM_CHUNK], d0[RM_CHUNK], d1[RM_CHUNK], c0[RM_CHUNK], c1[RM_CHUNK], c2[RM_CHUNK];
+        #pragma unroll
+        for (uint32_t j = 0; j < RM_CHUNK; j++) {
+            const uint32_t k = (k0 + j < num_steps) ? k0 + j : num_steps - 1;     // clamp: the tail re-reads the last sample
+            sv[j] = s[k]; d0[j] = dl[2 * k]; d1[j] = dl[2 * k + 1];
+            c0[j] = c[3 * k]; c1[j] = c[3 * k + 1]; c2[j] = c[3 * k + 2];
+        }
+        #pragma unroll
+        for (uint32_t j = 0; j < RM_CHUNK; j++) {
+            if (done || k0 + j >= num_steps) { done = true; continue; }
+            const float alpha = 1.0f - ngp_expf(-sv[j] * d0[j]);
+            const float w = alpha * T;
+            r += w * c0[j]; g += w * c1[j]; b += w * c2[j];
+            t += d1[j];
+            d += w * t;
+            ws += w;
+            T *= 1.0f - alpha;
+            if (T < 1e-4f) done = true;
+        }
     }
     weights_sum[index] = ws; depth[index] = d;
     image[3ull * index] = r; image[3ull * index + 1] = g; image[3ull * index + 2] = b;
@@ -358,18 +373,30 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_train_bwd(const float* _
     float* gs = grad_sigmas + offset;
     float* gc = grad_rgbs + 3ull * offset;
     float T = 1.0f, r = 0, g = 0, b = 0;
-    for (uint32_t k = 0; k < num_steps; k++) {
-        const float alpha = 1.0f - ngp_expf(-s[0] * dl[0]);
-        const float w = alpha * T;
-        r += w * c[0]; g += w * c[1]; b += w * c[2];
-        T *= 1.0f - alpha;
-        if (T < 1e-4f) break;
-        gc[0] = g0 * w; gc[1] = g1 * w; gc[2] = g2 * w;
-        gs[0] = dl[0] * (g0 * (T * c[0] - (rf - r)) +
-                         g1 * (T * c[1] - (gf - g)) +
-                         g2 * (T * c[2] - (bf - b)) +
-                         gws * (1.0f - wsf));
-        s++; c += 3; dl += 2; gs++; gc += 3;
+    bool done = false;                                 // chunked like the forward pass (see there)
+    for (uint32_t k0 = 0; k0 < num_steps && !done; k0 += RM_CHUNK) {
+        float sv[RM_CHUNK], d0[RM_CHUNK], c0[RM_CHUNK], c1[RM_CHUNK], c2[RM_CHUNK];
+        #pragma unroll
+        for (uint32_t j = 0; j < RM_CHUNK; j++) {
+            const uint32_t k = (k0 + j < num_steps) ? k0 + j : num_steps - 1;
+            sv[j] = s[k]; d0[j] = dl[2 * k];
+            c0[j] = c[3 * k]; c1[j] = c[3 * k + 1]; c2[j] = c[3 * k + 2];
+        }
+        #pragma unroll
+        for (uint32_t j = 0; j < RM_CHUNK; j++) {
+            if (done || k0 + j >= num_steps) { done = true; continue; }
+            const uint32_t k = k0 + j;
+            const float alpha = 1.0f - ngp_expf(-sv[j] * d0[j]);
+            const float w = alpha * T;
+            r += w * c0[j]; g += w * c1[j]; b += w * c2[j];
+            T *= 1.0f - alpha;
+            if (T < 1e-4f) { done = true; continue; }
+            gc[3 * k] = g0 * w; gc[3 * k + 1] = g1 * w; gc[3 * k + 2] = g2 * w;
+            gs[k] = d0[j] * (g0 * (T * c0[j] - (rf - r)) +
+                             g1 * (T * c1[j] - (gf - g)) +
+                             g2 * (T * c2[j] - (bf - b)) +
+                             gws * (1.0f - wsf));
+        }
     }
 }
 
