@@ -26,11 +26,6 @@
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 
-#ifndef RF_PAIR_LANES
-#define RF_PAIR_LANES 0                // 1: hashed levels: neighbouring lanes fetch the x-corner pair of one sample in one instruction
-#endif                                 // (half the L1 tag lookups, +64 VALU per tile).  A/B on MI355X: 5.2-5.4 ms with, 4.8-4.9 ms
-                                       // without: the texture path is busy per lane address (TA 70 %, TD 78 % busy), not per tag
-                                       // lookup, so merging lookups buys nothing and the DPP exchange costs VALU.  Off.
 #ifndef RF_MIX_BLEND
 #define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
 #endif
@@ -99,19 +94,17 @@ __device__ __forceinline__ void rf_setup_levels(const rf_params& P, int g, rf_la
 }
 
 // Which kind of code each iteration needs, decided once per kernel by the whole wave (bit i = iteration i).
-struct rf_iter_class { uint32_t dense, hashed, select, reuse; };   // reuse: the cell (x,y,z) of every level packs into 3 x 10 bits
+struct rf_iter_class { uint32_t dense, hashed, select; };
 
 __device__ __forceinline__ rf_iter_class rf_classify(const rf_lane_levels& lv) {   // call with all 64 lanes active
-    rf_iter_class c = {0u, 0u, 0u, 0u};
+    rf_iter_class c = {0u, 0u, 0u};
     #pragma unroll
     for (int i = 0; i < 4; i++) {
         const unsigned long long bd = __ballot(lv.s1b[i] != 0u), bh = __ballot(lv.mask4[i] != 0u);
         if (bd == ~0ull) c.dense |= 1u << i;                       // every lane: dense level
         else if (bh == ~0ull) c.hashed |= 1u << i;                 // every lane: hashed level with 2^k rows
         else if ((bd | bh) == ~0ull) c.select |= 1u << i;          // a mix of those two
-                                                                   // otherwise (a hashed level whose size is not 2^k): generic
-        if (__ballot(lv.scale[i] <= 1021.0f) == ~0ull) c.reuse |= 1u << i;   // cell index <= scale + 1.5 < 1024 on every axis
-    }
+    }                                                              // otherwise (a hashed level whose size is not 2^k): generic
     return c;
 }
 
@@ -149,13 +142,9 @@ __device__ __forceinline__ void rf_normalise(const rf_params& P, float wx, float
     else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
 }
 
-// REUSE (frame kernel): consecutive tiles of a lane group hold consecutive samples of the same 16 rays, 3.4 mm apart, and on
-// all but the finest levels a ray stays in one cell for several samples.  `o` then still holds that cell's 8 rows from the
-// previous tile: a lane whose cell (packed in `key`) has not changed skips its loads (and, when the whole wave skips, the
-// address arithmetic).  Same rows, same blend; about 40 % fewer gather lanes on the benchmark frame.
-template <int H, bool REUSE = false>
+template <int H>
 __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
-                                               float x0, float x1, float x2, rf_pair& o, uint32_t* key = nullptr) {
+                                               float x0, float x1, float x2, rf_pair& o) {
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;              // fast_hash primes (gridencoder.cu:35-51)
     // positions of the two levels at once: packed binary32 multiply and add (same roundings as the scalar operations)
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -170,12 +159,6 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
         const uint32_t gx = (uint32_t)flx, gy = (uint32_t)fly, gz = (uint32_t)flz;
         fx[i & 1] = px - flx; fy[i & 1] = py - fly; fz[i & 1] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
         const uint32_t bit = 1u << i;
-        if (REUSE && (cls.reuse & bit)) {
-            const uint32_t cell = gx | (gy << 10) | (gz << 20);
-            const bool same = cell == key[i];
-            key[i] = cell;
-            if (same) continue;
-        }
         if (cls.dense & bit) {
             // x + y*s1 + z*s2 (always < size); the x-neighbour is the next row: one 8-byte load per (y, z)
             const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + lv.base4[i]));
@@ -226,29 +209,6 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
                     off[c] = (dense ? id : ih) * 4u + lv.base4[i];
                 }
             }
-#if RF_PAIR_LANES
-            if (cls.hashed & bit) {
-                // The two x-corners of a sample are rows idx and idx ^ (x ^ (x+1)): almost always the same 128-byte line, but
-                // two load instructions are two L1 tag lookups.  Lanes s and s^1 (neighbouring columns of the tile) therefore
-                // swap work: instruction A fetches both x-corners of the EVEN lane's sample (even lane: x, odd lane: x+1),
-                // instruction B both of the ODD lane's sample; the two addresses of an instruction sit in adjacent lanes and
-                // coalesce into one lookup, and a DPP exchange hands each lane its own sample's rows.  Same rows, same blend;
-                // half the lookups of the hashed levels for 8 extra VALU per (y, z) pair.
-                const bool odd = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 1u) != 0u;   // lane parity
-                #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t o0 = off[2 * q], o1 = off[2 * q + 1];
-                    const uint32_t o1_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)o1, 0xA0, 0xf, 0xf, true);   // quad_perm [0,0,2,2]
-                    const uint32_t o0_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)o0, 0xF5, 0xf, 0xf, true);    // quad_perm [1,1,3,3]
-                    const uint32_t la = rf_row(P, odd ? o1_even : o0);
-                    const uint32_t lb = rf_row(P, odd ? o1 : o0_odd);
-                    const uint32_t lb_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)lb, 0xA0, 0xf, 0xf, true);
-                    const uint32_t la_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)la, 0xF5, 0xf, 0xf, true);
-                    raw[i & 1][2 * q] = odd ? lb_even : la;
-                    raw[i & 1][2 * q + 1] = odd ? lb : la_odd;
-                }
-            } else
-#endif
             {
                 #pragma unroll
                 for (int c = 0; c < 8; c++) raw[i & 1][c] = rf_row(P, off[c]);
@@ -504,10 +464,6 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
 #endif                                        // RV_S = 4 (80 KiB) only fit beside ONE copy of the weights per CU
-#ifndef RV_REUSE_ROWS
-#define RV_REUSE_ROWS 0                // 1: a lane keeps the 8 rows of a level while its ray stays in the same cell (rf_gather_pair).
-#endif                                 // A/B on MI355X: L1 accesses -23 %, TA busy -8 %, VALU +8 % (cell keys, exec masks), frame
-                                       // time 4.95-5.06 vs 4.85 ms: the frame does not respond to memory-side savings.  Off.
 #ifndef RV_PIPELINE
 #define RV_PIPELINE 0                  // 1: issue the next tile's hashed-level gathers before the current tile's MLP (software
 #endif                                 // pipeline across tiles).  A/B on MI355X: 5.0-5.2 ms with, 4.8-5.0 ms without: four waves per
@@ -685,32 +641,31 @@ __device__ __forceinline__ float rv_advance(const rv_consts& k, float t, float t
 // the 15 other waves of the CU); this takes almost all of them off the march's critical path.
 struct rv_block_cache { uint32_t blk = 0xffffffffu, lo = 0, hi = 0; };
 
-template <bool SKIP>
-__device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
-                                         float M, rv_block_cache& bc, float& t, float& x, float& y, float& z, float& dt
+// The occupancy test of one lattice point (coarse map, then the cached 64-bit word of the block): everything the reference
+// derives from t, and whether the cell is occupied.  `st` keeps what a following rv_leave needs.
+struct rv_tested { rv_point r; bool maybe; uint32_t sw; };
+
+__device__ __forceinline__ bool rv_test(const rv_view& m, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words, rv_block_cache& bc,
+                                        float tc, rv_tested& st
 #ifdef RV_COUNTERS
-                                         , int* rv_dbg_ptr
+                                        , int* rv_dbg_ptr
 #endif
-                                         ) {
-    const rv_view m(ray, k);
-    const float tc = t;
-    rv_point r;
+                                        ) {
+    rv_point& r = st.r;
     r.at(m, tc);
-    x = r.x; y = r.y; z = r.z; dt = r.dt;
     const uint32_t mort = ngp_morton3((uint32_t)r.nx, (uint32_t)r.ny, (uint32_t)r.nz);
-    bool occ;
-    bool maybe = true;
-    uint32_t sw = 0;
+    st.maybe = true;
+    st.sw = 0;
     if (lds_coarse) {
         const uint32_t blk = mort >> 6;
-        maybe = (lds_coarse[(uint32_t)r.level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u;
-        sw = (uint32_t)r.level * coarse_words + ((blk >> 6) << 1);       // the 64 coarse bits of the 16^3 block: 2 words
+        st.maybe = (lds_coarse[(uint32_t)r.level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u;
+        st.sw = (uint32_t)r.level * coarse_words + ((blk >> 6) << 1);    // the 64 coarse bits of the 16^3 block: 2 words
 #ifdef RV_COUNTERS
-        *rv_dbg_ptr = maybe ? 0 : ((lds_coarse[sw] | lds_coarse[sw + 1]) == 0u ? 2 : 1);
+        *rv_dbg_ptr = st.maybe ? 0 : ((lds_coarse[st.sw] | lds_coarse[st.sw + 1]) == 0u ? 2 : 1);
 #endif
     }
-    if (!maybe) occ = false;
-    else if (lds_coarse) {
+    if (!st.maybe) return false;
+    if (lds_coarse) {
         // with a coarse map the cell index level * H^3 + morton is exact in binary32 (host: C * H^3 <= 2^24), so the
         // reference's bit (raymarching.cu:783-784) is bit (morton & 63) of word level * H^3 / 64 + (morton >> 6)
         const uint32_t gblk = (uint32_t)r.level * (coarse_words << 5) + (mort >> 6);
@@ -718,15 +673,19 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
             const uint2 w = reinterpret_cast<const uint2*>(m.grid)[gblk];
             bc.blk = gblk; bc.lo = w.x; bc.hi = w.y;
         }
-        occ = (((mort & 32u) ? bc.hi : bc.lo) >> (mort & 31u)) & 1u;
-    } else {
-        const uint32_t index = (uint32_t)((float)r.level * m.H3 + (float)mort);
-        occ = (m.grid[index >> 3] >> (index & 7u)) & 1u;
+        return (((mort & 32u) ? bc.hi : bc.lo) >> (mort & 31u)) & 1u;
     }
-    if (occ) return true;
+    const uint32_t index = (uint32_t)((float)r.level * m.H3 + (float)mort);
+    return (m.grid[index >> 3] >> (index & 7u)) & 1u;
+}
+
+// Leave the empty cell tested at tc (state `st`): a verified block skip when the block is empty, else the reference's step.
+template <bool SKIP>
+__device__ __forceinline__ float rv_leave(const rv_view& m, const uint32_t* __restrict__ lds_coarse, float M, const rv_tested& st, float tc) {
+    const rv_point& r = st.r;
     const float tt = r.cell_exit(m, tc);
-    if (SKIP && lds_coarse && !maybe) {
-        const int sh = ((lds_coarse[sw] | lds_coarse[sw + 1]) == 0u) ? 4 : 2;
+    if (SKIP && lds_coarse && !st.maybe) {
+        const int sh = ((lds_coarse[st.sw] | lds_coarse[st.sw + 1]) == 0u) ? 4 : 2;
         const float tb = r.block_exit(m, tc, sh);
         const float target = tb - (2.0f * ngp_clampf(tb * m.dt_gamma, m.dt_min, m.dt_max) + M);
         if (target > tt) {                             // false when M is inf or NaN: such rays never skip
@@ -745,12 +704,31 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
                 const float te = q.cell_exit(m, ts);
                 float tp;
                 const float ta = rv_advance(m, ts, te, tp);
-                if ((te - tp) > M && (ta - te) > M) { t = ta; return false; }
+                if ((te - tp) > M && (ta - te) > M) return ta;
             }
         }
     }
     float tp;
-    t = rv_advance(m, tc, tt, tp);
+    return rv_advance(m, tc, tt, tp);
+}
+
+template <bool SKIP>
+__device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
+                                         float M, rv_block_cache& bc, float& t, float& x, float& y, float& z, float& dt
+#ifdef RV_COUNTERS
+                                         , int* rv_dbg_ptr
+#endif
+                                         ) {
+    const rv_view m(ray, k);
+    rv_tested st;
+#ifdef RV_COUNTERS
+    const bool occ = rv_test(m, lds_coarse, coarse_words, bc, t, st, rv_dbg_ptr);
+#else
+    const bool occ = rv_test(m, lds_coarse, coarse_words, bc, t, st);
+#endif
+    x = st.r.x; y = st.r.y; z = st.r.z; dt = st.r.dt;
+    if (occ) return true;
+    t = rv_leave<SKIP>(m, lds_coarse, M, st, t);
     return false;
 }
 
@@ -1120,7 +1098,7 @@ template <bool FIXED>
 __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame& F, const rf_iter_class cls_rt,
                                               const ngp_h8* __restrict__ lds_w, _Float16* lds_sh, const rf_lane_levels* lds_lv,
                                               float4* lds_smp, float* lds_d1, const uint32_t* lds_coarse) {
-    const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u, 7u} : cls_rt;
+    const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the same, known to be uniform
 
@@ -1308,10 +1286,6 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             if (__ballot(ccol > 0) == 0ull) continue;
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             const rf_lane_levels lv = lds_lv[g];
-#if RV_REUSE_ROWS
-            rf_pair pa, pb;                            // the rows of the previous tile (same rays, previous sample)
-            uint32_t key[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-#endif
             #pragma unroll 1
             for (int k = 0; k < RV_S; k++) {
                 if (__ballot(ccol > k) == 0ull) break;   // counts only shrink with k
@@ -1319,20 +1293,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 if (!(ccol > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);   // column without a k-th sample: harmless dummy
                 n_tiles++;
                 float a, b, c, d;
-#if RV_REUSE_ROWS
-                {
-                    float x0, x1, x2;
-                    rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
-                    rf_gather_pair<0, true>(P, lv, cls, x0, x1, x2, pa, key);
-                    rf_gather_pair<1, true>(P, lv, cls, x0, x1, x2, pb, key);
-                    ngp_h8 x;
-                    rf_blend_pair(pa, 0, x);
-                    rf_blend_pair(pb, 1, x);
-                    rv_mlp_tile(lds_w, lane, x, shq, a, b, c, d);
-                }
-#else
                 rv_field_tile(P, lv, cls, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
-#endif
                 if (g == 0 && ccol > k) {                // the half-precision network outputs replace (x, y) of the slot
                     ngp_h4 r;
                     r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
@@ -1429,7 +1390,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     }
     __syncthreads();
     const rf_iter_class cls = rf_classify(lds_lv[g]);
-    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u && cls.reuse == 7u)
+    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u)
         rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
     else
         rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
