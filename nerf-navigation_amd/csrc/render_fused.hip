@@ -456,14 +456,14 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 //   | packed-half ReLU, activations once per round, exact reciprocals 8.2 | RV_S = 4 samples per ray per round
 //   (1024 x 1, 156 KiB LDS) 6.85   (100 timed frames each; short runs scatter by +-10 %)
 #ifndef RV_S
-#define RV_S 4                         // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
+#define RV_S 5                         // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
 #endif
 #ifndef RV_BLOCK_THREADS
 #define RV_BLOCK_THREADS (RV_S > 1 ? 1024 : 512)
 #endif
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
-#endif                                        // RV_S = 4 (80 KiB) only fit beside ONE copy of the weights per CU
+#endif                                        // RV_S = 5 (80 KiB) only fit beside ONE copy of the weights per CU
 #ifndef RV_PIPELINE
 #define RV_PIPELINE 0                  // 1: issue the next tile's hashed-level gathers before the current tile's MLP (software
 #endif                                 // pipeline across tiles).  A/B on MI355X: 5.0-5.2 ms with, 4.8-5.0 ms without: four waves per
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
 // counts and statistics are identical to the one-sample kernel); the price is their field evaluation.
 // ---------------------------------------------------------------------------
 #if RV_S > 1
-static constexpr uint32_t RV_LDS_SMP = RV_WAVES * 64 * RV_S * 20;      // per sample: float4 (x, y, z, dt) + float d1
+static constexpr uint32_t RV_LDS_SMP = RV_WAVES * 64 * RV_S * 16;      // per sample: float4 (x, y, z, t before the step)
 
 // ---------------------------------------------------------------------------
 // Tile order.  A frame's rays differ a lot in cost (0 to a few hundred samples) and a lane only ever sees two or three
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
 template <bool FIXED>
 __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame& F, const rf_iter_class cls_rt,
                                               const ngp_h8* __restrict__ lds_w, _Float16* lds_sh, const rf_lane_levels* lds_lv,
-                                              float4* lds_smp, float* lds_d1, const uint32_t* lds_coarse) {
+                                              float4* lds_smp, const uint32_t* lds_coarse) {
     const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the same, known to be uniform
@@ -1105,7 +1105,6 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     _Float16* my_sh = lds_sh + (wave * 64 + lane) * 16;
     const _Float16* wave_sh = lds_sh + wave * 64 * 16;
     float4* my_smp = lds_smp + (wave * 64 + lane) * RV_S;               // this lane's sample slots
-    float* my_d1 = lds_d1 + (wave * 64 + lane) * RV_S;
     float4* wave_smp = lds_smp + wave * 64 * RV_S;
 
     // float conversions and divisions run on the vector ALU even for uniform inputs; rv_uniform moves the results to SGPRs
@@ -1191,7 +1190,6 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             // this lane's slots, recomputed from the lane id (2 VALU) rather than kept across the field evaluation in scratch
             const uint32_t slot0 = ((uint32_t)wave_s * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) * RV_S;
             float4* const smp_w = lds_smp + slot0;
-            float* const d1_w = lds_d1 + slot0;
             int probes = 0;
             for (;;) {
 #ifdef RV_COUNTERS
@@ -1207,10 +1205,8 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
 #else
                 if (rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt)) {
 #endif
+                    smp_w[cnt] = make_float4(x, y, z, t);     // the compositor re-derives dt and t - last_t from t (same operations)
                     t += dt;
-                    smp_w[cnt] = make_float4(x, y, z, dt);
-                    d1_w[cnt] = t - last_t;
-                    last_t = t;
                     nsamp++;
                     if (++cnt == RV_S) break;
                 }
@@ -1227,6 +1223,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         RV_TICK(c_march)
         // ---- field evaluation: for each group of 16 rays, tile k = their k-th samples ----
 #if RV_PIPELINE
+        static_assert(RV_S <= 4, "the tile list of RV_PIPELINE packs k in two bits");
         {
             // Software pipeline across tiles: the gathers of the hashed half of the NEXT tile (levels 8+g, 12+g: the slow
             // ones) are issued before the MLP of the current tile, so a wave keeps the texture path busy while it sits in
@@ -1312,7 +1309,13 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         bool done = false;
         for (int k = 0; k < cnt; k++) {
             const ngp_h4 r = *reinterpret_cast<const ngp_h4*>(&my_smp[k]);
-            const float dt = my_smp[k].w, d1 = my_d1[k];
+            // what the march computed for this sample (rv_point::at and kernel_march_rays, raymarching.cu:786-790), re-derived
+            // from the sample's t instead of being stored: 16-byte slots leave room for a fifth sample per lane
+            const float ts = my_smp[k].w;
+            const float dt = ngp_clampf(ts * K.dt_gamma, K.dt_min, K.dt_max);
+            const float ta = ts + dt;
+            const float d1 = ta - last_t;
+            last_t = ta;
             float sig = (float)r[0], sr = (float)r[1], sg = (float)r[2], sb = (float)r[3];
             rv_activate(P, sig, sr, sg, sb);
             n_samples_local++;
@@ -1362,7 +1365,6 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
     rf_lane_levels* lds_lv = reinterpret_cast<rf_lane_levels*>(rv_smem + RV_LDS_W + RV_LDS_SH);
     float4* lds_smp = reinterpret_cast<float4*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV);
-    float* lds_d1 = reinterpret_cast<float*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_WAVES * 64 * RV_S * 16);
     uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_SMP) : nullptr;
 
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
@@ -1391,9 +1393,9 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     __syncthreads();
     const rf_iter_class cls = rf_classify(lds_lv[g]);
     if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u)
-        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
+        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse);
     else
-        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_d1, lds_coarse);
+        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse);
 }
 #endif  // RV_S > 1
 
