@@ -231,8 +231,11 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
         tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
     }
 
+    uint32_t pair_row[2] = {0u, 0u}, pair_val[2] = {0u, 0u};
+    int pair_act[2] = {0, 0};
     #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        bool send = true;
         float wi = 1;
         uint32_t pl[D];
         #pragma unroll
@@ -254,14 +257,45 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
                     for (uint32_t c = 0; c < N_C; c++) v[c] += o[c];
                 }
             }
-            if (!(tail && valid)) continue;
             bool zero = true;                          // padding rows and samples behind a saturated ray carry exact zeros
             #pragma unroll
             for (uint32_t c = 0; c < N_C; c++) zero = zero && v[c] == 0.0f;
-            if (zero) continue;
+            send = tail && valid && !zero;
+            if (sizeof(T) != 2 && !send) continue;     // (the half path exchanges with the neighbouring lane first)
         }
         const uint64_t row = (uint64_t)ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C + ch;
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 && AGG) {
+            // Float atomics execute at the memory side as 64-byte requests (about 20 G requests/s chip-wide, which is what
+            // this kernel runs at): lanes of ONE instruction that hit the same 64-byte line share a request.  The two
+            // x-neighbours of a sample are rows idx and idx ^ (x ^ (x+1)): the same line 15 times out of 16, but as two
+            // instructions they are two requests.  So neighbouring lanes swap work: one instruction carries both x-corners
+            // of the even lane's sample (even lane: x, odd lane: x+1), the next both of the odd lane's.
+            static_assert(N_C == 2, "half scatter needs feature pairs");
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 hv;
+            hv.x = (_Float16)v[0];                     // (__half)(w * grad) : gridencoder.cu:302
+            hv.y = (_Float16)v[1];
+            pair_row[idx & 1u] = (uint32_t)row;
+            pair_val[idx & 1u] = __builtin_bit_cast(uint32_t, hv);
+            pair_act[idx & 1u] = send ? 1 : 0;
+            if (idx & 1u) {
+                const bool odd = (lane & 1) != 0;
+                // quad_perm [0,0,2,2] = 0xA0: odd lanes read their even neighbour;  [1,1,3,3] = 0xF5: even lanes read their odd neighbour
+                // (all six exchanges are evaluated by every lane BEFORE any selection: inside a conditional expression only the
+                //  lanes taking that side would be active, and a DPP read of a switched-off lane returns 0)
+                const uint32_t row1_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)pair_row[1], 0xA0, 0xf, 0xf, true);
+                const uint32_t val1_even = (uint32_t)__builtin_amdgcn_mov_dpp((int)pair_val[1], 0xA0, 0xf, 0xf, true);
+                const int act1_even = __builtin_amdgcn_mov_dpp(pair_act[1], 0xA0, 0xf, 0xf, true);
+                const uint32_t row0_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)pair_row[0], 0xF5, 0xf, 0xf, true);
+                const uint32_t val0_odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)pair_val[0], 0xF5, 0xf, 0xf, true);
+                const int act0_odd = __builtin_amdgcn_mov_dpp(pair_act[0], 0xF5, 0xf, 0xf, true);
+                const uint32_t rowA = odd ? row1_even : pair_row[0], valA = odd ? val1_even : pair_val[0];
+                const uint32_t rowB = odd ? pair_row[1] : row0_odd, valB = odd ? pair_val[1] : val0_odd;
+                const int actA = odd ? act1_even : pair_act[0], actB = odd ? pair_act[1] : act0_odd;
+                if (actA) __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gg + rowA), __builtin_bit_cast(h2, valA));
+                if (actB) __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gg + rowB), __builtin_bit_cast(h2, valB));
+            }
+        } else if constexpr (sizeof(T) == 2) {
             static_assert(sizeof(T) != 2 || N_C == 2, "half scatter needs feature pairs");
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             h2 hv;
