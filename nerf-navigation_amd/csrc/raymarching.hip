@@ -14,6 +14,10 @@ extern "C" int ngp_abi_version(void) { return 1; }
 extern "C" const char* ngp_last_error(void) { return ngp_err_buf; }
 
 static constexpr uint32_t RM_BLOCK = 256;
+// Kernels with one lane per RAY run long sequential loops over few rays (4,096 per training step; the alive set of the
+// inference loop shrinks to a few thousand): 64-thread workgroups spread those waves over 4x as many CUs, each with its own
+// L1 / texture path, instead of packing four per CU and leaving most of the chip idle.
+static constexpr uint32_t RM_RAY_BLOCK = 64;
 static constexpr uint32_t RM_CHUNK = 8;         // samples fetched ahead by the per-ray composite loops
 
 // ---------------------------------------------------------------------------
@@ -163,7 +167,8 @@ __device__ __forceinline__ float train_t0(const ngp_march_t& m, float near, uint
     return near + m.dt_min * rng.next_float();
 }
 
-// block-wide inclusive scan of one uint per thread (4 waves): wave scan by DPP-free shuffles, then wave totals in LDS
+// block-wide inclusive scan of one uint per thread (NW waves): wave scan by DPP-free shuffles, then wave totals in LDS
+template <uint32_t NW>
 __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* lds4, uint32_t& block_total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t s = v;
@@ -176,7 +181,7 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* l
     __syncthreads();
     uint32_t base = 0, total = 0;
     #pragma unroll
-    for (uint32_t w = 0; w < RM_BLOCK / 64; w++) {
+    for (uint32_t w = 0; w < NW; w++) {
         const uint32_t t = lds4[w];
         if (w < wave) base += t;
         total += t;
@@ -186,11 +191,11 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* l
     return s + base;
 }
 
-__global__ __launch_bounds__(RM_BLOCK) void k_march_train_count(march_args a, int* __restrict__ rays,
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a, int* __restrict__ rays,
                                                                 const int* __restrict__ counter,
                                                                 uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t lds4[RM_BLOCK / 64];
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     uint32_t num_steps = 0;
     if (n < a.N) {
         ngp_march_t m;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_count(march_args a, in
         if (slot < a.N) rays[3ull * slot + 2] = (int)num_steps;      // stash; the write pass completes the record
     }
     uint32_t total;
-    (void)block_inclusive_scan(num_steps, lds4, total);
+    (void)block_inclusive_scan<RM_RAY_BLOCK / 64>(num_steps, lds4, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restr
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
         uint32_t total;
-        const uint32_t inc = block_inclusive_scan(v, lds4, total);
+        const uint32_t inc = block_inclusive_scan<RM_BLOCK / 64>(v, lds4, total);
         const uint32_t c = carry;
         if (i < nblocks) block_sums[i] = c + inc - v;
         __syncthreads();
@@ -236,19 +241,19 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restr
     }
 }
 
-__global__ __launch_bounds__(RM_BLOCK) void k_march_train_write(march_args a, int* __restrict__ rays,
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a, int* __restrict__ rays,
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 const uint32_t* __restrict__ bases,
                                                                 float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                 float* __restrict__ deltas) {
-    __shared__ uint32_t lds4[RM_BLOCK / 64];
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     const uint32_t ray_base = bases[1];
     const uint32_t slot = ray_base + n;
     const bool live = (n < a.N) && (slot < a.N);
     const uint32_t num_steps = live ? (uint32_t)rays[3ull * slot + 2] : 0u;
     uint32_t total;
-    const uint32_t inc = block_inclusive_scan(num_steps, lds4, total);
+    const uint32_t inc = block_inclusive_scan<RM_RAY_BLOCK / 64>(num_steps, lds4, total);
     if (!live) return;
     const uint32_t point_index = block_sums[blockIdx.x] + inc - num_steps;
     rays[3ull * slot] = (int)n;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_write(march_args a, in
 }
 
 extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) {
-    return sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_BLOCK) + 4);
+    return sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4);
 }
 
 extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -291,14 +296,14 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays_train: bad C/H/max_steps");
     NGP_REQUIRE(workspace && workspace_bytes >= ngp_march_rays_train_workspace(N), "march_rays_train: workspace too small");
     if (N == 0) return NGP_OK;
-    const uint32_t nblocks = ngp_div_up(N, RM_BLOCK);
+    const uint32_t nblocks = ngp_div_up(N, RM_RAY_BLOCK);
     uint32_t* block_sums = (uint32_t*)workspace;
     uint32_t* bases = block_sums + nblocks;
     march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, N, C, H, M, perturb};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, a, rays, counter, block_sums);
+    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, counter, block_sums);
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
-    hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas);
+    hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas);
     NGP_CHECK_LAUNCH("march_rays_train");
     return NGP_OK;
 }
@@ -307,12 +312,12 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
 // training composite
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(RM_BLOCK) void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                                   const float* __restrict__ deltas, const int* __restrict__ rays,
                                                                   uint32_t M, uint32_t N, float* __restrict__ weights_sum,
                                                                   float* __restrict__ depth, float* __restrict__ image) {
     // reference: raymarching.cu:506-582
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
     if (num_steps == 0 || offset + num_steps >= M) {
@@ -353,14 +358,14 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_train_fwd(const float* _
     image[3ull * index] = r; image[3ull * index + 1] = g; image[3ull * index + 2] = b;
 }
 
-__global__ __launch_bounds__(RM_BLOCK) void k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
                                                                   const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                                   const float* __restrict__ deltas, const int* __restrict__ rays,
                                                                   const float* __restrict__ weights_sum, const float* __restrict__ image,
                                                                   uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
                                                                   float* __restrict__ grad_rgbs) {
     // reference: raymarching.cu:607-688
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
     if (num_steps == 0 || offset + num_steps >= M) return;
@@ -406,7 +411,7 @@ extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float
     NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null sample pointer");
     if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(ngp_div_up(N, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
                        sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
     NGP_CHECK_LAUNCH("composite_rays_train_forward");
     return NGP_OK;
@@ -420,7 +425,7 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
     NGP_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, "composite_rays_train_backward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), "composite_rays_train_backward: null sample pointer");
     if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(ngp_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(ngp_div_up(N, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
                        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
     NGP_CHECK_LAUNCH("composite_rays_train_backward");
     return NGP_OK;
@@ -430,11 +435,11 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
 // inference march / composite
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(RM_BLOCK) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
                                                          const float* __restrict__ rays_t, march_args a,
                                                          float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
     // reference: raymarching.cu:707-814
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     ngp_march_t m;
@@ -463,13 +468,13 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_rays(uint32_t n_alive, uint3
     }
 }
 
-__global__ __launch_bounds__(RM_BLOCK) void k_composite_rays(uint32_t n_alive, uint32_t n_step, int* __restrict__ rays_alive,
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_rays(uint32_t n_alive, uint32_t n_step, int* __restrict__ rays_alive,
                                                              float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                              const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                              float* __restrict__ weights_sum, float* __restrict__ depth,
                                                              float* __restrict__ image) {
     // reference: raymarching.cu:829-913
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     const float* s = sigmas + (uint64_t)n * n_step;
@@ -506,7 +511,7 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
     if (n_alive == 0 || n_step == 0) return NGP_OK;
     march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, 0u, C, H, 0u, perturb};
-    hipLaunchKernelGGL(k_march_rays, dim3(ngp_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_march_rays, dim3(ngp_div_up(n_alive, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
                        n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
     NGP_CHECK_LAUNCH("march_rays");
     return NGP_OK;
@@ -517,7 +522,7 @@ extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* ra
     if (n_alive == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "composite_rays: null pointer");
     if (n_alive == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_rays, dim3(ngp_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_composite_rays, dim3(ngp_div_up(n_alive, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
                        n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
     NGP_CHECK_LAUNCH("composite_rays");
     return NGP_OK;
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_compact_scan(uint32_t* __restrict_
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
         uint32_t total;
-        const uint32_t inc = block_inclusive_scan(v, lds4, total);
+        const uint32_t inc = block_inclusive_scan<RM_BLOCK / 64>(v, lds4, total);
         const uint32_t c = carry;
         if (i < nblocks) block_sums[i] = c + inc - v;
         __syncthreads();
