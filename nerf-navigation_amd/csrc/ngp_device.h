@@ -165,87 +165,4 @@ __device__ __forceinline__ void ngp_near_far_inline(const float* o, const float*
 
 #define NGP_SKIP_GUARD 65536   // bound on the empty-space substep loop (the reference's is unbounded: :400-402)
 
-struct ngp_march_t {
-    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
-    const uint8_t* grid;
-    // The 64 cells of a 4^3 block are one aligned 64-bit word of the bitfield (Morton order).  A ray tests dozens of points
-    // per block, so the word it last loaded is kept: one 8-byte load per block entered instead of one dependent byte load
-    // per test (the march is latency-bound on exactly that load).  Only when the reference's binary32 cell index
-    // (raymarching.cu:383) is exact, C * H^3 <= 2^24, and H is a power of two; otherwise the byte path below.
-    uint32_t blocks_per_level;        // H^3 / 64, or 0: no block cache
-    uint32_t c_blk, c_lo, c_hi;
-
-    __device__ __forceinline__ void setup(const float* o, const float* d, float bound_, float dt_gamma_,
-                                          uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid_) {
-        ox = o[0]; oy = o[1]; oz = o[2];
-        dx = d[0]; dy = d[1]; dz = d[2];
-        rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
-        bound = bound_; dt_gamma = dt_gamma_;
-        Hf = (float)H; Cf = (float)C; Hm1 = (float)(H - 1);
-        rH = 1.0f / Hf;
-        H3 = (float)(H * H * H);
-        dt_min = (2.0f * 1.7320508075688772f) / (float)max_steps;
-        dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (C - 1))) / Hf;
-        grid = grid_;
-        const bool exact = (H & (H - 1u)) == 0u && H >= 4u && (uint64_t)C * H * H * H <= (1ull << 24) &&
-                           (reinterpret_cast<uintptr_t>(grid_) & 7u) == 0u;
-        blocks_per_level = exact ? (H * H * H) >> 6 : 0u;
-        c_blk = 0xffffffffu; c_lo = 0u; c_hi = 0u;
-    }
-
-    __device__ __forceinline__ int mip(int e) const {
-        return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e));
-    }
-
-    // Probe at parameter t.  Occupied: returns true with the sample (x,y,z,dt), t untouched.
-    // Empty: returns false after moving t past the cell (DDA to the exit face, then dt substeps).
-    __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt) {
-        const float tc = t;
-        x = ngp_clampf(ox + tc * dx, -bound, bound);
-        y = ngp_clampf(oy + tc * dy, -bound, bound);
-        z = ngp_clampf(oz + tc * dz, -bound, bound);
-        dt = ngp_clampf(tc * dt_gamma, dt_min, dt_max);
-
-        int e_pos, e_dt;
-        (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
-        (void)frexpf((dt * Hf) * 0.5f, &e_dt);          // *0.5 is exact, so float == the reference's double product
-        const int lp = mip(e_pos), ld = mip(e_dt);
-        const int level = lp > ld ? lp : ld;
-
-        const float mip_bound = fminf((float)(1 << level), bound);
-        const float mip_rbound = 1.0f / mip_bound;
-
-        // reference :378-380 evaluates 0.5*(..)*H in double; halving is exact, so one float rounding is identical
-        const int nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * Hf, 0.0f, Hm1);
-        const int ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * Hf, 0.0f, Hm1);
-        const int nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * Hf, 0.0f, Hm1);
-
-        const uint32_t mort = ngp_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-        bool occ;
-        if (blocks_per_level) {
-            const uint32_t gblk = (uint32_t)level * blocks_per_level + (mort >> 6);
-            if (gblk != c_blk) {
-                const uint2 w = reinterpret_cast<const uint2*>(grid)[gblk];
-                c_blk = gblk; c_lo = w.x; c_hi = w.y;
-            }
-            occ = (((mort & 32u) ? c_hi : c_lo) >> (mort & 31u)) & 1u;
-        } else {
-            const uint32_t index = (uint32_t)((float)level * H3 + (float)mort);
-            occ = (grid[index >> 3] >> (index & 7u)) & 1u;
-        }
-        if (occ) return true;
-
-        const float tx = (((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH) * 2.0f - 1.0f) * mip_bound - x) * rdx;
-        const float ty = (((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH) * 2.0f - 1.0f) * mip_bound - y) * rdy;
-        const float tz = (((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH) * 2.0f - 1.0f) * mip_bound - z) * rdz;
-        const float tt = tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        float tn = tc;
-        int guard = 0;
-        do {
-            tn += ngp_clampf(tn * dt_gamma, dt_min, dt_max);
-        } while (tn < tt && ++guard < NGP_SKIP_GUARD);
-        t = tn;
-        return false;
-    }
-};
+// (ngp_march_t, the per-ray march state of the per-op kernels, lives in ngp_march.h)

@@ -6,7 +6,7 @@
 // N/256 workgroups -- >= 2500 for an 800x800 frame, enough to fill 256 CUs several times over.  The occupancy
 // bitfield (cascade * 128^3 / 8 = 0.5 MB at bound 2) is L2-resident; the kernels are bound by the divergent
 // per-ray loops, not by HBM.
-#include "ngp_device.h"
+#include "ngp_march.h"
 
 thread_local char ngp_err_buf[512] = {0};
 
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
         ngp_march_t m;
         m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
         const float far = a.fars[n];
+        m.allow_skip(a.C, a.H, far);
         float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
         while (t < far && num_steps < a.max_steps) {
             if (m.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a
     ngp_march_t m;
     m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
     const float far = a.fars[n];
+    m.allow_skip(a.C, a.H, far);
     float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
     float last_t = t;
     uint32_t step = 0;
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, u
     float* pl = deltas + 2ull * n * n_step;
     float t = rays_t[index];
     const float far = a.fars[index];
+    m.allow_skip(a.C, a.H, far);
     if (a.perturb) {                                  // seed = perturb, jump = alive SLOT (reference :752-755,819)
         ngp_pcg32 rng; rng.seed((uint64_t)a.perturb);
         rng.advance((uint64_t)n);

@@ -25,6 +25,7 @@
 // reference offers between max_steps and max_steps+7 depending on the schedule; such rays are counted in stats[1]).
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
+#include "ngp_march.h"
 
 #ifndef RF_MIX_BLEND
 #define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
@@ -532,109 +533,8 @@ struct rv_view : rv_ray, rv_consts {                   // what rv_probe reads: p
     __device__ __forceinline__ rv_view(const rv_ray& r, const rv_consts& k) : rv_ray(r), rv_consts(k) {}
 };
 
-// One march sample point: everything kernel_march_rays derives from t (raymarching.cu:748-781), same arithmetic.
-struct rv_point {
-    float x, y, z, dt, mip_bound;
-    int level, nx, ny, nz;
-    __device__ __forceinline__ void at(const rv_view& m, float tc) {
-        x = ngp_clampf(m.ox + tc * m.dx, -m.bound, m.bound);
-        y = ngp_clampf(m.oy + tc * m.dy, -m.bound, m.bound);
-        z = ngp_clampf(m.oz + tc * m.dz, -m.bound, m.bound);
-        dt = ngp_clampf(tc * m.dt_gamma, m.dt_min, m.dt_max);
-        int e_pos, e_dt;
-        (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e_pos);
-        (void)frexpf((dt * m.Hf) * 0.5f, &e_dt);
-        const int lp = m.mip(e_pos), ld = m.mip(e_dt);
-        level = lp > ld ? lp : ld;
-        const float p2 = (float)(1 << level);
-        mip_bound = fminf(p2, m.bound);
-        // 1 / mip_bound without a division per probe: 2^-level is exact and 1 / bound is the same IEEE quotient, computed once
-        const float mip_rbound = (p2 <= m.bound) ? __builtin_ldexpf(1.0f, -level) : m.rbound;
-        nx = (int)ngp_clampf(((x * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
-        ny = (int)ngp_clampf(((y * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
-        nz = (int)ngp_clampf(((z * mip_rbound + 1.0f) * 0.5f) * m.Hf, 0.0f, m.Hm1);
-    }
-    // ray parameter at which the ray leaves this point's cell (raymarching.cu:792-797)
-    __device__ __forceinline__ float cell_exit(const rv_view& m, float tc) const {
-        const float tx = (((((float)nx + 0.5f + 0.5f * copysignf(1.0f, m.dx)) * m.rH) * 2.0f - 1.0f) * mip_bound - x) * m.rdx;
-        const float ty = (((((float)ny + 0.5f + 0.5f * copysignf(1.0f, m.dy)) * m.rH) * 2.0f - 1.0f) * mip_bound - y) * m.rdy;
-        const float tz = (((((float)nz + 0.5f + 0.5f * copysignf(1.0f, m.dz)) * m.rH) * 2.0f - 1.0f) * mip_bound - z) * m.rdz;
-        return tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-    }
-    // the same for the aligned block of 2^sh cells per axis around the cell (an estimate: only used to choose a skip target)
-    __device__ __forceinline__ float block_exit(const rv_view& m, float tc, int sh) const {
-        const float bs = (float)(1 << sh);
-        const float tx = ((((((float)(nx >> sh) + 0.5f + 0.5f * copysignf(1.0f, m.dx)) * bs) * m.rH) * 2.0f - 1.0f) * mip_bound - x) * m.rdx;
-        const float ty = ((((((float)(ny >> sh) + 0.5f + 0.5f * copysignf(1.0f, m.dy)) * bs) * m.rH) * 2.0f - 1.0f) * mip_bound - y) * m.rdy;
-        const float tz = ((((((float)(nz >> sh) + 0.5f + 0.5f * copysignf(1.0f, m.dz)) * bs) * m.rH) * 2.0f - 1.0f) * mip_bound - z) * m.rdz;
-        return tc + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-    }
-};
+typedef ngp_point<rv_view> rv_point;             // one march sample point (ngp_march.h)
 
-// ngp_march_t::probe with the coarse map in front of the fine bit, and verified skips through empty blocks.
-//
-// The reference leaves an empty cell by stepping t += dt until t passes the cell's exit (raymarching.cu:792-801).  The
-// step depends on t alone, so the points t_0 = near, t_{k+1} = t_k + dt(t_k) form a fixed lattice per ray; the reference
-// tests the first lattice point in every cell that holds one, and every lattice point of an occupied cell is a sample.
-// When the whole 4^3 (or 16^3) block around an empty cell is empty, those tests can only fail, so the march may jump over
-// them -- provided it rejoins the reference's sequence of tested points exactly.  It does so as follows (r = current
-// point, all in the reference's own arithmetic):
-//   1. move along the lattice to a point s short of the block's exit by a guard distance (constant step: in closed form,
-//      rv_lattice_jump; dt_gamma > 0: a bounded walk);
-//   2. evaluate s as the reference would (level, cell): s must lie in the same block at the same level.  Cell indices are
-//      monotone in t on every axis, so every lattice point between r and s then lies in that block as well, and block
-//      alignment with the cascade boundaries (H a power of two >= 64, bound a power of two or a single cascade: decided
-//      on the host, F.skip) keeps those points on the same level: whatever the reference tested in between was empty;
-//   3. take the reference's step from s to the first lattice point a beyond the exit e(s) of s's cell.  The reference
-//      arrives in that cell at some lattice point p (p <= s, or the point after s when s sits on the cell's entry face)
-//      and steps from there beyond e(p).  e(p) and e(s) measure the same face; they differ by rounding only, by less than
-//      the per-ray bound M (see rv_skip_margin).  If no lattice point lies within M of e(s), both steps end on the same
-//      point a, which is therefore a point the reference tests: the skip is accepted and the march continues from a;
-//   4. in every other case the probe takes the reference's ordinary one-cell step from r.
-// The per-op kernels (raymarching.hip) never skip; tests/test_gpu_fullsize.py checks per-ray equality against them.
-// Lattice points of a CONSTANT step inside one binade are equally spaced.  With u the binade's ulp, t = T u and
-// dt = (c + f) u, |f| < 1/2, the sum t + dt rounds to (T + c) u whatever T is, as long as it stays below the binade's end:
-// k steps from t land exactly on t + k (c u), and c u is what one real step adds.  (|f| = 1/2 would round to even and
-// alternate; it is detected from the step's rounding error and not used.)  Returns the lattice point reached from t by
-// one real step plus as many whole steps as stay below min(lim, end of t's binade): every operation here is exact.
-__device__ __forceinline__ float rv_lattice_jump(float t, float dtc, float lim) {
-    const float t1 = t + dtc;                          // the reference's own step
-    const float du = t1 - t;                           // exact (Sterbenz): what that step added
-    int e;
-    (void)frexpf(t, &e);                               // t in [2^(e-1), 2^e), ulp 2^(e-24)
-    const float end = fminf(lim, __builtin_ldexpf(1.0f, e));
-    const float err = dtc - du;                        // exact: rounding error of t + dtc
-    if (!(t1 < end) || !(du > 0.0f) || fabsf(err) == __builtin_ldexpf(1.0f, e - 25)) return t1;
-    // j <= (end - t1) / du - 1 keeps t1 + j du below `end` whatever the rounding of the estimate (relative error ~1e-6)
-    const float j = floorf((end - t1) * __builtin_amdgcn_rcpf(du)) - 1.0f;
-    return j > 0.0f ? t1 + j * du : t1;                // j du < 2^(e-1) is a multiple of u: both operations exact
-}
-
-// The reference's step out of an empty cell (raymarching.cu:798-801): do { t += dt(t); } while (t < tt).  Returns the first
-// lattice point >= tt after at least one step, and in `prev` the lattice point before it.  With a constant step most of the
-// way is one exact multiply-add (rv_lattice_jump lands strictly below tt, or on the single step t + dt); the last steps
-// are real steps, so the result is the reference's bit for bit.
-__device__ __forceinline__ float rv_advance(const rv_consts& k, float t, float tt, float& prev) {
-    float tn;
-    int guard = 0;
-    if (k.dt_gamma == 0.0f) {
-        const float dtc = ngp_clampf(0.0f, k.dt_min, k.dt_max);
-        prev = t;
-        tn = rv_lattice_jump(t, dtc, tt);
-        while (tn < tt && ++guard < NGP_SKIP_GUARD) { prev = tn; tn += dtc; }
-    } else {
-        tn = t;
-        do {
-            prev = tn;
-            tn += ngp_clampf(tn * k.dt_gamma, k.dt_min, k.dt_max);
-        } while (tn < tt && ++guard < NGP_SKIP_GUARD);
-    }
-    return tn;
-}
-
-#ifndef RV_SKIP_WALK
-#define RV_SKIP_WALK 32
-#endif
 // The 64 cells of a 4^3 block are one aligned 64-bit word of the bitfield (Morton order).  A ray tests dozens of lattice
 // points per block, so the word it last loaded stays in registers: one 8-byte load per block entered instead of one byte
 // load per test.  Under load a dependent global load costs the march thousands of cycles (it queues behind the gathers of
@@ -679,37 +579,19 @@ __device__ __forceinline__ bool rv_test(const rv_view& m, const uint32_t* __rest
     return (m.grid[index >> 3] >> (index & 7u)) & 1u;
 }
 
-// Leave the empty cell tested at tc (state `st`): a verified block skip when the block is empty, else the reference's step.
+// Leave the empty cell tested at tc (state `st`): a verified block skip when the block is empty (ngp_march.h), else the
+// reference's step.
 template <bool SKIP>
 __device__ __forceinline__ float rv_leave(const rv_view& m, const uint32_t* __restrict__ lds_coarse, float M, const rv_tested& st, float tc) {
     const rv_point& r = st.r;
     const float tt = r.cell_exit(m, tc);
     if (SKIP && lds_coarse && !st.maybe) {
         const int sh = ((lds_coarse[st.sw] | lds_coarse[st.sw + 1]) == 0u) ? 4 : 2;
-        const float tb = r.block_exit(m, tc, sh);
-        const float target = tb - (2.0f * ngp_clampf(tb * m.dt_gamma, m.dt_min, m.dt_max) + M);
-        if (target > tt) {                             // false when M is inf or NaN: such rays never skip
-            // step 1: s only has to be a lattice point inside the block, the further the better
-            float ts = tc;
-            int guard = 0;
-            if (m.dt_gamma == 0.0f) ts = rv_lattice_jump(tc, ngp_clampf(0.0f, m.dt_min, m.dt_max), target);
-            else {
-                do {                                   // a varying step has no closed form: walk, at most RV_SKIP_WALK steps
-                    ts += ngp_clampf(ts * m.dt_gamma, m.dt_min, m.dt_max);
-                } while (ts < target && ++guard < RV_SKIP_WALK);
-            }
-            rv_point q;
-            q.at(m, ts);
-            if (q.level == r.level && (q.nx >> sh) == (r.nx >> sh) && (q.ny >> sh) == (r.ny >> sh) && (q.nz >> sh) == (r.nz >> sh)) {
-                const float te = q.cell_exit(m, ts);
-                float tp;
-                const float ta = rv_advance(m, ts, te, tp);
-                if ((te - tp) > M && (ta - te) > M) return ta;
-            }
-        }
+        const float ta = ngp_try_skip(m, r, tc, tt, sh, M);
+        if (ta >= 0.0f) return ta;
     }
     float tp;
-    return rv_advance(m, tc, tt, tp);
+    return ngp_advance(m, tc, tt, tp);
 }
 
 template <bool SKIP>
@@ -732,16 +614,6 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
     return false;
 }
 
-// Bound on how far two evaluations of one cell face's ray parameter (rv_point::cell_exit from two points of the cell)
-// can differ.  cell_exit = t + (plane - x(t)) * (1/d): the plane is exact (H and the cascade bound are powers of two),
-// x(t) = o + t d carries two roundings of magnitude <= 2^-24 (|o| + 2 |x|) <= 2^-24 (|o| + 2 bound), the difference one more,
-// the product with 1/d two more, the final sum one of 2^-24 t.  The bound below is 8x that estimate; a ray with a
-// vanishing direction component gets M = inf and never skips.
-__device__ __forceinline__ float rv_skip_margin(const rv_ray& r, float bound, float far) {
-    const float pos = fmaxf(fabsf(r.ox), fmaxf(fabsf(r.oy), fabsf(r.oz))) + 4.0f * bound;
-    const float rd = fmaxf(fabsf(r.rdx), fmaxf(fabsf(r.rdy), fabsf(r.rdz)));
-    return 4.8e-7f * (pos * rd + fabsf(far));           // 8 * 2^-24 = 4.8e-7
-}
 
 __device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int f, int lane) { return lds_w[f * 64 + lane]; }
 
@@ -1046,7 +918,7 @@ __global__ __launch_bounds__(256) void k_tile_estimate(rf_frame F, float bound, 
     K.dt_min = (2.0f * 1.7320508075688772f) / (float)F.max_steps;
     K.dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / K.Hf;
     K.grid = F.bitfield;
-    const float M = F.skip ? rv_skip_margin(m, bound, far) : __builtin_inff();
+    const float M = F.skip ? ngp_skip_margin(m, bound, far) : __builtin_inff();
     float t = near;
     uint32_t n = 0;
     int probes = 0;
@@ -1186,7 +1058,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             // vector registers; a copy per round keeps every memory access out of the probe loop
             rv_consts Kr = K;
             asm("" : "+v"(Kr.Hf), "+v"(Kr.Hm1), "+v"(Kr.Cf), "+v"(Kr.rH), "+v"(Kr.dt_min), "+v"(Kr.dt_max), "+v"(Kr.rbound), "+v"(Kr.H3));
-            const float M = F.skip ? rv_skip_margin(mr, K.bound, far_r) : __builtin_inff();
+            const float M = F.skip ? ngp_skip_margin(mr, K.bound, far_r) : __builtin_inff();
             // this lane's slots, recomputed from the lane id (2 VALU) rather than kept across the field evaluation in scratch
             const uint32_t slot0 = ((uint32_t)wave_s * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) * RV_S;
             float4* const smp_w = lds_smp + slot0;

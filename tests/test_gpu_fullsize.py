@@ -186,8 +186,9 @@ def test_block_skipping_changes_nothing(full, oracle, dev, scene, dt_gamma, pose
 def test_fused_march_gives_every_ray_the_single_march_sample_count(full, oracle, dev, scene, pose):
     """Constant density, constant step (dt_gamma 0), no saturation: a ray's weights_sum depends on its sample count alone
     and strictly increases with it.  The counts come from march_rays_train (one march from near to far, bit-exact against
-    the oracle in test_gpu_raymarching.py): rays with equal counts must have bit-equal weights_sum, more samples more
-    weight -- i.e. the fused march (with block skipping) gave each of the 640,000 rays exactly that many samples."""
+    the cell-by-cell CPU oracle in test_gpu_raymarching.py; it finds empty 16^3 blocks by OR-ing bitfield words, the fused
+    kernel through its LDS map): rays with equal counts must have bit-equal weights_sum, more samples more weight --
+    i.e. the fused march gave each of the 640,000 rays exactly that many samples."""
     import raymarching
     W = full["W"]
     ren = _constant_density_renderer(dev, _scene_grid(W, oracle, scene), 1e-3)
