@@ -33,10 +33,11 @@
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
 #ifndef RF_PROBES_PER_ROUND
-#define RF_PROBES_PER_ROUND 128        // march iterations a round may spend so that every lane can collect its RV_S samples.
+#define RF_PROBES_PER_ROUND 512        // march iterations a round may spend so that every lane can collect its RV_S samples.
 #endif                                 // A/B on MI355X, ms per frame.  Before block skipping (each probe = one cell): 4: 26.0,
                                        // 8: 19.9, 16: 12.5, 32: 12.2, 48: 12.6.  With block skipping and RV_S = 4: 6: 6.62, 10: 5.82,
-                                       // 16: 5.26, 24: 4.98, 32: 4.83, 48: 4.60, 64: 4.5-4.8, 128: 4.40, 256: 4.41, 1024: 4.58
+                                       // 16: 5.26, 24: 4.98, 32: 4.83, 48: 4.60, 64: 4.5-4.8, 128: 4.40, 256: 4.41, 1024: 4.58.
+                                       // With RV_S = 12 (512 threads): 64: 4.59, 128: 4.33, 256: 4.2, 512: 4.05
 
 struct rf_params {
     const uint32_t* table;            // [sO] half2 rows
@@ -456,15 +457,18 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 //   | 512 x 2 (4 waves/SIMD, 128 VGPR, 24 B/lane scratch) 9.2 | + 4x4 patches 9.1
 //   | packed-half ReLU, activations once per round, exact reciprocals 8.2 | RV_S = 4 samples per ray per round
 //   (1024 x 1, 156 KiB LDS) 6.85   (100 timed frames each; short runs scatter by +-10 %)
+// Once the frame had become VALU-bound what counts is how full a round is, i.e. how many samples per lane it
+// holds, and LDS bounds that: 1024 threads x 5 samples 4.33 | 768 x 7 4.24 | 512 x 12 (2 waves/SIMD, 256 VGPRs, no scratch;
+// march budget 512) 4.05 | 512 x 10 4.57 | 512 x 8 4.25.
 #ifndef RV_S
-#define RV_S 5                         // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
+#define RV_S 12                        // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
 #endif
 #ifndef RV_BLOCK_THREADS
-#define RV_BLOCK_THREADS (RV_S > 1 ? 1024 : 512)
+#define RV_BLOCK_THREADS 512
 #endif
 #ifndef RV_BLOCKS_PER_CU
-#define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // 16 waves per CU = 4 waves per SIMD either way; the sample slots of
-#endif                                        // RV_S = 5 (80 KiB) only fit beside ONE copy of the weights per CU
+#define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // the sample slots (96 KiB at 512 x 12) only fit beside ONE copy of the weights per CU
+#endif
 #ifndef RV_PIPELINE
 #define RV_PIPELINE 0                  // 1: issue the next tile's hashed-level gathers before the current tile's MLP (software
 #endif                                 // pipeline across tiles).  A/B on MI355X: 5.0-5.2 ms with, 4.8-5.0 ms without: four waves per
@@ -1327,7 +1331,9 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     const uint64_t blocks_per_level = (uint64_t)Hgrid * Hgrid * Hgrid / 64;
     const uint64_t coarse_bytes = (uint64_t)C * blocks_per_level / 8;
     // (C * H^3 <= 2^24: the reference forms the cell index in binary32, raymarching.cu:783; beyond that it rounds)
-    if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && coarse_bytes <= 48 * 1024 && (uint64_t)C * Hgrid * Hgrid * Hgrid <= (1ull << 24) &&
+    // and the map has to fit in the LDS left beside the weights, SH and sample slots (8 KiB for 2 cascades of 128^3; from 3
+    // cascades on it does not: such a frame is marched without the map, i.e. cell by cell through the bitfield itself)
+    if (rv_pow2(Hgrid) && Hgrid >= 8 && blocks_per_level % 32 == 0 && lds + coarse_bytes <= 160 * 1024 && (uint64_t)C * Hgrid * Hgrid * Hgrid <= (1ull << 24) &&
         workspace_bytes >= RV_WS_COARSE + coarse_bytes && (reinterpret_cast<uintptr_t>(bitfield) & 7u) == 0) {
         uint32_t* coarse = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + RV_WS_COARSE);
         const uint32_t n_blocks_total = (uint32_t)(C * blocks_per_level);

@@ -99,3 +99,29 @@ def test_repeatable_bit_for_bit(dev):
     a = ren.render_fused(t(o, dev)[None], t(d, dev)[None], bg_color=1, image_width=64)
     b = ren.render_fused(t(o, dev)[None], t(d, dev)[None], bg_color=1, image_width=64)
     assert torch.equal(a["image"], b["image"]) and torch.equal(a["weights_sum"], b["weights_sum"]) and torch.equal(a["stats"][:3], b["stats"][:3])
+
+
+def test_three_cascades_without_the_lds_map(oracle, dev):
+    """bound 4 = 3 cascades: the coarse occupancy map (12 KiB) no longer fits beside the sample slots, so the frame kernel
+    marches through the bitfield itself (no map, no block skipping).  Same answer as the oracle."""
+    from _util import blob_bitfield, camera_rays
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    bound = 4.0
+    rng = np.random.default_rng(11)
+    offsets, pls = W.grid_offsets(bound)
+    model = dict(W.make_model(0), bound=bound, offsets=offsets, per_level_scale=pls,
+                 embeddings=(rng.uniform(-1, 1, size=(int(offsets[-1]), 2)) * 0.25).astype(np.float32))
+    field = NGPFieldFF(bound=bound).to(dev).load_arrays(model)
+    ren = NGPRenderer(field, bound=bound, cuda_ray=True, density_thresh=0.5).to(dev).eval()
+    assert ren.cascade == 3
+    bitfield, grid = blob_bitfield(oracle, 3, 128, seed=4, n_blobs=30, bound=bound)
+    ren.load_density_grid(grid)
+    assert np.array_equal(ren.density_bitfield.cpu().numpy(), bitfield)
+    o, d = camera_rays(24, radius=5.5, seed=3)
+    ref = R.render_single_march(lambda x, dd: R.field_forward(model, x, dd, 1.0), o, d, bitfield, bound, 3)
+    out = ren.render_fused(t(o, dev)[None], t(d, dev)[None], bg_color=1)
+    stats = out["stats"].cpu().numpy()
+    assert abs(int(stats[0]) - ref["samples"]) <= max(8, 2e-3 * ref["samples"]) and stats[0] > 1000
+    assert np.max(np.abs(out["image"][0].cpu().numpy() - ref["image"])) < 8e-3
