@@ -474,453 +474,6 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #endif                                 // tiles).  A/B on MI355X: at 4 waves/SIMD (hashed half prefetched) 5.0-5.2 vs 4.8-5.0 ms; at
                                        // 2 waves/SIMD (whole tile prefetched, 208 VGPRs) 4.17-4.30 vs 4.12-4.36 ms: the frame is bound
                                        // by VALU throughput, not by the latency a prefetch would hide.  Off.
-#ifndef RF_MIX_BLEND
-#define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
-#endif
-static constexpr int RF_L = 16;       // levels (4 per lane group)
-static constexpr uint32_t RF_BLOCK = 256;
-#ifndef RF_PROBES_PER_ROUND
-#define RF_PROBES_PER_ROUND 512        // march iterations a round may spend so that every lane can collect its RV_S samples.
-#endif                                 // A/B on MI355X, ms per frame.  Before block skipping (each probe = one cell): 4: 26.0,
-                                       // 8: 19.9, 16: 12.5, 32: 12.2, 48: 12.6.  With block skipping and RV_S = 4: 6: 6.62, 10: 5.82,
-                                       // 16: 5.26, 24: 4.98, 32: 4.83, 48: 4.60, 64: 4.5-4.8, 128: 4.40, 256: 4.41, 1024: 4.58.
-                                       // With RV_S = 12 (512 threads): 64: 4.59, 128: 4.33, 256: 4.2, 512: 4.05
-
-struct rf_params {
-    const uint32_t* table;            // [sO] half2 rows
-    const int* offsets;               // [17]
-    const _Float16* w_sigma;          // 64*(32+64+16)
-    const _Float16* w_color;          // 64*(32+128+16)
-    float bound, density_scale;
-    float inv_b2;                     // 1 / (2 bound) when that is exact (2 bound a power of two), else 0
-    float scale[RF_L];                // exp2f(l*S)*H - 1 (host)
-    uint32_t resolution[RF_L];        // ceil(scale)+1
-    sh_norm shn;
-};
-
-// Level -> lane mapping.  Lane group g = lane >> 4 gathers, in iteration i = 0..3, level 4i + g, and holds its two
-// features at slots 2i, 2i+1 of the first layer's B fragment (the first layer's A fragments are loaded in that same k
-// order, rf_load_a_sigma_in).  Interleaving the levels over the lane groups makes an ITERATION nearly uniform across the
-// wave: in the reference's 16-level grid, iteration 0 is levels 0..3 (all dense), iterations 2 and 3 are levels 8..15
-// (all hashed) and only iteration 1 (levels 4..7) mixes both kinds, so three of four iterations run straight-line code
-// for one kind of level instead of executing both sides of a per-lane branch.
-struct rf_lane_levels {
-    float scale[4];
-    uint32_t base4[4];                         // byte offset of the level's first row in the table
-    uint32_t size[4];                          // rows
-    uint32_t s1b[4], s2b[4];                   // dense level: y and z strides in BYTES; s1b == 0 marks a hashed level
-    uint32_t mask4[4];                         // hashed level with 2^k rows: (rows - 1) * 4, else 0
-};
-
-__device__ __forceinline__ void rf_setup_levels(const rf_params& P, int g, rf_lane_levels& lv) {
-    #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        // select by lane group from the scalar (kernarg) arrays
-        float sc = P.scale[4 * i]; uint32_t rs = P.resolution[4 * i];
-        if (g == 1) { sc = P.scale[4 * i + 1]; rs = P.resolution[4 * i + 1]; }
-        if (g == 2) { sc = P.scale[4 * i + 2]; rs = P.resolution[4 * i + 2]; }
-        if (g == 3) { sc = P.scale[4 * i + 3]; rs = P.resolution[4 * i + 3]; }
-        const int level = 4 * i + g;
-        const uint32_t o0 = (uint32_t)P.offsets[level], o1 = (uint32_t)P.offsets[level + 1];
-        const uint32_t size = o1 - o0;
-        // reference get_grid_index (gridencoder.cu:54-72): the stride stops growing once it exceeds hashmap_size
-        uint32_t stride = 1, s1 = 0, s2 = 0;
-        bool dense = true;
-        #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            if (stride <= size) {
-                if (d == 1) s1 = stride;
-                if (d == 2) s2 = stride;
-                stride *= (rs + 1);
-            } else dense = false;
-        }
-        if (stride > size) dense = false;
-        if (rs + 1 > 1024u) dense = false;     // keeps the 24-bit multiplies of the dense path exact; such a level is hashed anyway
-        lv.scale[i] = sc; lv.base4[i] = o0 * 4u; lv.size[i] = size;
-        lv.s1b[i] = dense ? s1 * 4u : 0u; lv.s2b[i] = dense ? s2 * 4u : 0u;
-        lv.mask4[i] = (!dense && (size & (size - 1)) == 0) ? (size - 1) * 4u : 0u;
-    }
-}
-
-// Which kind of code each iteration needs, decided once per kernel by the whole wave (bit i = iteration i).
-struct rf_iter_class { uint32_t dense, hashed, select; };
-
-__device__ __forceinline__ rf_iter_class rf_classify(const rf_lane_levels& lv) {   // call with all 64 lanes active
-    rf_iter_class c = {0u, 0u, 0u};
-    #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned long long bd = __ballot(lv.s1b[i] != 0u), bh = __ballot(lv.mask4[i] != 0u);
-        if (bd == ~0ull) c.dense |= 1u << i;                       // every lane: dense level
-        else if (bh == ~0ull) c.hashed |= 1u << i;                 // every lane: hashed level with 2^k rows
-        else if ((bd | bh) == ~0ull) c.select |= 1u << i;          // a mix of those two
-    }                                                              // otherwise (a hashed level whose size is not 2^k): generic
-    return c;
-}
-
-__device__ __forceinline__ float rf_h(float v) { return (float)(_Float16)v; }   // round to half, back to float
-
-struct rf_row2 { uint32_t lo, hi; };                                          // two consecutive rows
-__device__ __forceinline__ uint32_t rf_row(const rf_params& P, uint32_t byte_off) {
-    asm("" : "+v"(byte_off));      // keep the 32-bit offset a VGPR value of its own: the load is then SGPR base + VGPR offset
-    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(P.table) + byte_off);
-}
-__device__ __forceinline__ rf_row2 rf_rows(const rf_params& P, uint32_t byte_off) {   // one 8-byte load, 4-byte aligned
-    asm("" : "+v"(byte_off));
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    typedef u2 u2_a4 __attribute__((aligned(4)));
-    const u2 v = *reinterpret_cast<const u2_a4*>(reinterpret_cast<const char*>(P.table) + byte_off);
-    return rf_row2{v.x, v.y};
-}
-
-// Hash-grid encoding of one sample for the 4 levels of this lane's group -> 8 half features (slot 2i + ch = level 4i + g).
-// Arithmetic identical, operation for operation, to k_grid_forward<_Float16,3,2> (gridencoder.hip); only the address
-// computation is arranged differently (byte offsets, strides folded into multiply-adds, the hash computed pre-shifted:
-// (y * p) << 2 == y * (p << 2) mod 2^32, and the power-of-two modulo taken on the operands: (a ^ b) & m == (a & m) ^ (b & m)).
-// INRANGE: the caller guarantees |w| <= bound (march samples are clamped to the box, raymarching.cu:365-367), so the
-// normalised position is in [0,1] and the out-of-range handling is dead code.
-// The gathers of one PAIR of iterations (h = 0: levels g and 4+g, h = 1: levels 8+g and 12+g) for a normalised position:
-// cell, fractions, byte offsets, loads issued (nothing waits here).  Splitting the encoder in pairs lets the frame kernel
-// issue the next tile's pair 1 (the hashed levels, the slow gathers) before the current tile's MLP (RV_PIPELINE).
-struct rf_pair { uint32_t raw[2][8]; float fx[2], fy[2], fz[2]; };
-
-__device__ __forceinline__ void rf_normalise(const rf_params& P, float wx, float wy, float wz, float& x0, float& x1, float& x2) {
-    // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound).  When 2*bound is a power of two (every cascade-aligned
-    // bound) the quotient equals the product with the exact reciprocal, bit for bit, and skips three IEEE divisions.
-    const float b2 = 2 * P.bound;
-    if (P.inv_b2 != 0.0f) { x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2; }
-    else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
-}
-
-template <int H>
-__device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
-                                               float x0, float x1, float x2, rf_pair& o) {
-    constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;              // fast_hash primes (gridencoder.cu:35-51)
-    // positions of the two levels at once: packed binary32 multiply and add (same roundings as the scalar operations)
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 sc2 = {lv.scale[2 * H], lv.scale[2 * H + 1]};
-    const f2 ppx = x0 * sc2 + 0.5f, ppy = x1 * sc2 + 0.5f, ppz = x2 * sc2 + 0.5f;
-    uint32_t (&raw)[2][8] = o.raw;
-    float (&fx)[2] = o.fx; float (&fy)[2] = o.fy; float (&fz)[2] = o.fz;
-    #pragma unroll
-    for (int i = 2 * H; i < 2 * H + 2; i++) {
-        const float px = ppx[i & 1], py = ppy[i & 1], pz = ppz[i & 1];
-        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-        const uint32_t gx = (uint32_t)flx, gy = (uint32_t)fly, gz = (uint32_t)flz;
-        fx[i & 1] = px - flx; fy[i & 1] = py - fly; fz[i & 1] = pz - flz;        // == px - (float)gx: the floor is an exact small integer
-        const uint32_t bit = 1u << i;
-        if (cls.dense & bit) {
-            // x + y*s1 + z*s2 (always < size); the x-neighbour is the next row: one 8-byte load per (y, z)
-            const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + lv.base4[i]));
-            const uint32_t o01 = o00 + lv.s1b[i], o10 = o00 + lv.s2b[i], o11 = o01 + lv.s2b[i];
-            const rf_row2 r0 = rf_rows(P, o00), r1 = rf_rows(P, o01), r2 = rf_rows(P, o10), r3 = rf_rows(P, o11);
-            raw[i & 1][0] = r0.lo; raw[i & 1][1] = r0.hi; raw[i & 1][2] = r1.lo; raw[i & 1][3] = r1.hi;
-            raw[i & 1][4] = r2.lo; raw[i & 1][5] = r2.hi; raw[i & 1][6] = r3.lo; raw[i & 1][7] = r3.hi;
-        } else {
-            uint32_t off[8];                                           // byte offsets of the 8 corners
-            if (cls.hashed & bit) {
-                const uint32_t m = lv.mask4[i], b = lv.base4[i];
-                const uint32_t hy = gy * (P1 << 2), hz = gz * (P2 << 2);
-                const uint32_t hy1 = hy + (P1 << 2), hz1 = hz + (P2 << 2);
-                const uint32_t a0 = (gx << 2) & m, a1 = ((gx << 2) + 4u) & m;
-                const uint32_t yz0 = (hy ^ hz) & m, yz1 = (hy1 ^ hz) & m, yz2 = (hy ^ hz1) & m, yz3 = (hy1 ^ hz1) & m;
-                off[0] = (a0 ^ yz0) + b; off[1] = (a1 ^ yz0) + b; off[2] = (a0 ^ yz1) + b; off[3] = (a1 ^ yz1) + b;
-                off[4] = (a0 ^ yz2) + b; off[5] = (a1 ^ yz2) + b; off[6] = (a0 ^ yz3) + b; off[7] = (a1 ^ yz3) + b;
-#ifdef RV_EXPERIMENT_WINDOW        // timing-only build: levels 8..15 gather inside a window of this many bytes per level
-                if (i >= 2) {
-                    #pragma unroll
-                    for (int c = 0; c < 8; c++) off[c] = b + ((off[c] - b) & (uint32_t)(RV_EXPERIMENT_WINDOW - 1));
-                }
-#endif
-            } else if (cls.select & bit) {
-                // both kinds in one wave: compute both offsets, select per lane, no branch
-                const bool dense = lv.s1b[i] != 0u;
-                const uint32_t m = lv.mask4[i], b = lv.base4[i];
-                const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + b));
-                const uint32_t o01 = o00 + lv.s1b[i], o10 = o00 + lv.s2b[i], o11 = o01 + lv.s2b[i];
-                const uint32_t hy = gy * (P1 << 2), hz = gz * (P2 << 2);
-                const uint32_t hy1 = hy + (P1 << 2), hz1 = hz + (P2 << 2);
-                const uint32_t a0 = (gx << 2) & m, a1 = ((gx << 2) + 4u) & m;
-                const uint32_t yz0 = (hy ^ hz) & m, yz1 = (hy1 ^ hz) & m, yz2 = (hy ^ hz1) & m, yz3 = (hy1 ^ hz1) & m;
-                off[0] = dense ? o00 : (a0 ^ yz0) + b; off[1] = dense ? o00 + 4u : (a1 ^ yz0) + b;
-                off[2] = dense ? o01 : (a0 ^ yz1) + b; off[3] = dense ? o01 + 4u : (a1 ^ yz1) + b;
-                off[4] = dense ? o10 : (a0 ^ yz2) + b; off[5] = dense ? o10 + 4u : (a1 ^ yz2) + b;
-                off[6] = dense ? o11 : (a0 ^ yz3) + b; off[7] = dense ? o11 + 4u : (a1 ^ yz3) + b;
-            } else {
-                // generic: any mix, including a hashed level whose row count is not a power of two (index % size);
-                // branch-free like the rest, so that the choice of class stays the only (wave-uniform) control flow
-                const bool dense = lv.s1b[i] != 0u;
-                const uint32_t s1 = lv.s1b[i] >> 2, s2 = lv.s2b[i] >> 2;
-                const uint32_t hy = gy * P1, hz = gz * P2;
-                #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const uint32_t id = (gx + (c & 1)) + (gy * s1 + ((c & 2) ? s1 : 0u)) + (gz * s2 + ((c & 4) ? s2 : 0u));
-                    const uint32_t ih = ((gx + (c & 1)) ^ (hy + ((c & 2) ? P1 : 0u)) ^ (hz + ((c & 4) ? P2 : 0u))) % lv.size[i];
-                    off[c] = (dense ? id : ih) * 4u + lv.base4[i];
-                }
-            }
-            {
-                #pragma unroll
-                for (int c = 0; c < 8; c++) raw[i & 1][c] = rf_row(P, off[c]);
-            }
-        }
-    }
-}
-
-// Blend of one level.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):
-//   w = (wx * wy) * wz in binary32;  results[ch] += w * grid[...]  ==  half(float(result) + float(half(w * float(v))))
-// RF_MIX_BLEND: v_fma_mixlo/mixhi_f16 compute half(fma32(w, float(v), +0)) in one instruction per feature -- the same
-// two roundings (binary32 product, then binary16) as the cvt / mul / cvt sequence; the +0 addend only turns a -0 product
-// into +0, which a sum that starts at +0 cannot tell apart.  The packed-half add is the correctly rounded binary16 sum.
-__device__ __forceinline__ void rf_blend_pair(const rf_pair& in, int h, ngp_h8& out) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const f2 wx = {1 - in.fx[j], in.fx[j]};
-        const float wy0 = 1 - in.fy[j], wz0 = 1 - in.fz[j];
-        const f2 wxy0 = wx * wy0, wxy1 = wx * in.fy[j];
-        const f2 w[4] = {wxy0 * wz0, wxy1 * wz0, wxy0 * in.fz[j], wxy1 * in.fz[j]};   // (y, z) = (0,0) (1,0) (0,1) (1,1)
-        h2 acc = {(_Float16)0.0f, (_Float16)0.0f};
-        #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const float wc = w[c >> 1][c & 1];
-#if RF_MIX_BLEND
-            uint32_t prod;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(prod) : "v"(wc), "v"(in.raw[j][c]));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(prod) : "v"(wc), "v"(in.raw[j][c]));
-            acc = acc + __builtin_bit_cast(h2, prod);
-#else
-            const h2 v = __builtin_bit_cast(h2, in.raw[j][c]);
-            const h2 prod = {(_Float16)(wc * (float)v.x), (_Float16)(wc * (float)v.y)};
-            acc = acc + prod;
-#endif
-        }
-        out[4 * h + 2 * j] = acc.x;
-        out[4 * h + 2 * j + 1] = acc.y;
-    }
-}
-
-template <bool INRANGE = false>
-__device__ __forceinline__ ngp_h8 rf_encode(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
-                                            float wx, float wy, float wz) {
-    float x0, x1, x2;
-    rf_normalise(P, wx, wy, wz, x0, x1, x2);
-    // a sample outside [0,1]^3 encodes to zeros (gridencoder.cu:118-131); it gathers at the origin so that no load needs a guard
-    const bool oob = !INRANGE && ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
-    if (oob) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; }
-    rf_pair a, b;
-    rf_gather_pair<0>(P, lv, cls, x0, x1, x2, a);
-    rf_gather_pair<1>(P, lv, cls, x0, x1, x2, b);
-    ngp_h8 out;
-    rf_blend_pair(a, 0, out);
-    rf_blend_pair(b, 1, out);
-    if (oob) {
-        #pragma unroll
-        for (int j = 0; j < 8; j++) out[j] = (_Float16)0.0f;
-    }
-    return out;
-}
-
-// density-net first layer, A fragments in rf_encode's k order: slots 2i, 2i+1 of lane group g = features of level 4i + g
-__device__ __forceinline__ ngp_h8 rf_load_a_sigma_in(const _Float16* __restrict__ W, int t, int lane) {
-    const int row = 16 * t + (lane & 15), g = lane >> 4;
-    ngp_h8 a;
-    #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        a[2 * i] = W[row * 32 + 2 * (4 * i + g)];
-        a[2 * i + 1] = W[row * 32 + 2 * (4 * i + g) + 1];
-    }
-    return a;
-}
-
-// colour-net first layer, A fragments in the k order {h[4g..4g+3], SH[4g..4g+3]} (see the header comment)
-__device__ __forceinline__ ngp_h8 rf_load_a_color_in(const _Float16* __restrict__ W, int t, int lane) {
-    const int row = 16 * t + (lane & 15), g = lane >> 4;
-    ngp_h8 a;
-    #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int hi = 4 * g + j;                      // index into the density net's output h
-        a[j] = (hi == 0) ? (_Float16)0.0f : W[row * 32 + 15 + hi];   // geo feature hi-1 sits at input column 16 + (hi-1)
-        a[4 + j] = W[row * 32 + 4 * g + j];            // SH feature 4g+j
-    }
-    return a;
-}
-
-struct rf_weights {
-    mlp_weights<1, 1> sig;                             // FFMLP(32 -> 64 -> 64 -> 16), num_layers 2
-    ngp_h8 c_in[MLP_MT];
-    ngp_h8 c_hid[2][MLP_MT][2];                        // FFMLP(32 -> 64 -> 64 -> 64 -> 16), num_layers 3
-    ngp_h8 c_out[2];
-    __device__ __forceinline__ void load(const rf_params& P, int lane) {
-        sig.load(P.w_sigma, 32, lane);
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) sig.w_in[t][0] = rf_load_a_sigma_in(P.w_sigma, t, lane);
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) c_in[t] = rf_load_a_color_in(P.w_color, t, lane);
-        const _Float16* Wh = P.w_color + MLP_W * 32;
-        #pragma unroll
-        for (int h = 0; h < 2; h++)
-            #pragma unroll
-            for (int t = 0; t < MLP_MT; t++)
-                #pragma unroll
-                for (int c = 0; c < 2; c++) c_hid[h][t][c] = mlp_load_a_permuted(Wh + h * MLP_W * MLP_W, MLP_W, t, c, lane);
-        #pragma unroll
-        for (int c = 0; c < 2; c++) c_out[c] = mlp_load_a_permuted(Wh + 2 * MLP_W * MLP_W, MLP_W, 0, c, lane);
-    }
-};
-
-// One 16-column tile: (world position, direction) of column s's sample, held redundantly by its 4 lanes.
-// Returns, valid in lanes g == 0: sigma (already times density_scale) and rgb.
-__device__ __forceinline__ void rf_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls, const rf_weights& W, int g,
-                                              float px, float py, float pz, float dx, float dy, float dz,
-                                              float& sigma, float& cr, float& cg, float& cb) {
-    ngp_h8 x[1];
-    x[0] = rf_encode(P, lv, cls, px, py, pz);
-    const ngp_f4 h = mlp_forward_tile<1, 1>(W.sig, x, [](int, const ngp_h8 (&)[2]) {});
-
-    float sh[16];
-    sh_eval<4>(dx, dy, dz, P.shn, sh);
-    ngp_h8 cin;
-    #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        cin[j] = (_Float16)h[j];                       // density-net output, rounded to half (FFMLP output dtype)
-        float s = sh[j];
-        if (g == 1) s = sh[4 + j];
-        if (g == 2) s = sh[8 + j];
-        if (g == 3) s = sh[12 + j];
-        cin[4 + j] = (_Float16)s;                      // cat(...) enters FFMLP through cast_inputs=half
-    }
-    ngp_h8 act[2];
-    {
-        ngp_f4 d[MLP_MT];
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(W.c_in[t], cin, ngp_f4{0.f, 0.f, 0.f, 0.f});
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
-    }
-    #pragma unroll
-    for (int l = 0; l < 2; l++) {
-        ngp_f4 d[MLP_MT];
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) {
-            d[t] = ngp_mfma(W.c_hid[l][t][0], act[0], ngp_f4{0.f, 0.f, 0.f, 0.f});
-            d[t] = ngp_mfma(W.c_hid[l][t][1], act[1], d[t]);
-        }
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
-    }
-    ngp_f4 o = ngp_mfma(W.c_out[0], act[0], ngp_f4{0.f, 0.f, 0.f, 0.f});
-    o = ngp_mfma(W.c_out[1], act[1], o);
-
-    // lanes g == 0 hold h0 (row 0 of the density tile) and rows 0..2 of the colour tile
-    sigma = P.density_scale * ngp_expf(rf_h(h[0]));                                   // trunc_exp forward (activation.py:9-10), fp32
-    cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[0]))));                                 // torch.sigmoid on a half tensor
-    cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[1]))));
-    cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[2]))));
-}
-
-// ---------------------------------------------------------------------------
-// field_forward: sigma / rgb for explicit points
-// ---------------------------------------------------------------------------
-
-__global__ __launch_bounds__(RF_BLOCK) void k_field_forward(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
-                                                            uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
-    const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
-    rf_lane_levels lv;
-    rf_setup_levels(P, g, lv);
-    const rf_iter_class cls = rf_classify(lv);
-    rf_weights W;
-    W.load(P, lane);
-    const uint32_t ntiles = (M + 15) >> 4;
-    for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
-        const uint32_t m = tile * 16 + s;
-        const bool valid = m < M;
-        const uint64_t mm = valid ? m : 0;
-        const float px = xyzs[3 * mm], py = xyzs[3 * mm + 1], pz = xyzs[3 * mm + 2];
-        const float dx = dirs[3 * mm], dy = dirs[3 * mm + 1], dz = dirs[3 * mm + 2];
-        float sigma, cr, cg, cb;
-        rf_field_tile(P, lv, cls, W, g, px, py, pz, dx, dy, dz, sigma, cr, cg, cb);
-        if (g == 0 && valid) {
-            sigmas[m] = sigma;
-            rgbs[3ull * m] = cr; rgbs[3ull * m + 1] = cg; rgbs[3ull * m + 2] = cb;
-        }
-    }
-}
-
-static int rf_fill_params(const char* who, const ngp_field_t* f, rf_params& P) {
-    NGP_REQUIRE(f && f->embeddings && f->offsets && f->sigma_weights && f->color_weights, "%s: null field pointer", who);
-    NGP_REQUIRE(f->L == RF_L, "%s: the fused path is built for 16 levels x 2 features (the reference's hashgrid)", who);
-    NGP_REQUIRE(f->bound > 0, "%s: bound must be positive", who);
-    P.table = (const uint32_t*)f->embeddings;
-    P.offsets = f->offsets;
-    P.w_sigma = (const _Float16*)f->sigma_weights;
-    P.w_color = (const _Float16*)f->color_weights;
-    P.bound = f->bound;
-    P.density_scale = f->density_scale;
-    {
-        int e;
-        const float b2 = 2.0f * f->bound;
-        P.inv_b2 = (frexpf(b2, &e) == 0.5f) ? 1.0f / b2 : 0.0f;
-    }
-    for (int l = 0; l < RF_L; l++) {
-        P.scale[l] = exp2f((float)l * f->S) * (float)f->H - 1.0f;
-        P.resolution[l] = (uint32_t)ceilf(P.scale[l]) + 1u;
-    }
-    sh_fill_norm(P.shn);
-    return NGP_OK;
-}
-
-extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
-                                 float* sigmas, float* rgbs, void* stream) {
-    rf_params P;
-    int rc = rf_fill_params("field_forward", field_host, P);
-    if (rc != NGP_OK) return rc;
-    if (M == 0) return NGP_OK;
-    NGP_REQUIRE(xyzs && dirs && sigmas && rgbs, "field_forward: null pointer");
-    const uint32_t ntiles = (M + 15) >> 4;
-    uint32_t blocks = ngp_div_up(ntiles, 4 * 4);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_field_forward, dim3(blocks), dim3(RF_BLOCK), 0, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs);
-    NGP_CHECK_LAUNCH("field_forward");
-    return NGP_OK;
-}
-
-// ---------------------------------------------------------------------------
-// render_frame: one persistent 1024-thread workgroup per CU (16 waves, 1024 rays in flight), one ray per lane,
-// ray queue in global memory.  LDS per workgroup:
-//   [0, 36 KiB)        the 36 MFMA weight fragments of both networks, fragment-major (lane l reads 16 B at 16*l:
-//                      conflict-free ds_read_b128), so no weight occupies a VGPR and 4 waves fit per SIMD;
-//   [36 KiB, +C*4 KiB) coarse occupancy: one bit per 4x4x4 block of density-grid cells.  In Morton order such a
-//                      block is 64 consecutive bits = 8 consecutive bytes of the bitfield, so the coarse bit is
-//                      just "those 8 bytes != 0".  A probe whose block is empty never touches global memory:
-//                      the dependent global load leaves the march's critical path in empty space, and the decision
-//                      is identical to reading the fine bit (empty block => empty cell);
-//   [.., +16*2 KiB)    the 16 SH coefficients (half) of each lane's current ray, written once per ray.
-// ---------------------------------------------------------------------------
-
-// Tuning knobs, each A/B-measured on MI355X with tools/ab_variants.sh (800x800 S-ring frame, ms per frame):
-//   256 thr x 2/CU (2 waves/SIMD) 16.8 | 256 x 3 (3 waves/SIMD, 164 VGPR) 12.2 | + paired loads (136 VGPR) 10.5
-//   | 512 x 2 (4 waves/SIMD, 128 VGPR, 24 B/lane scratch) 9.2 | + 4x4 patches 9.1
-//   | packed-half ReLU, activations once per round, exact reciprocals 8.2 | RV_S = 4 samples per ray per round
-//   (1024 x 1, 156 KiB LDS) 6.85   (100 timed frames each; short runs scatter by +-10 %)
-// Once the frame had become VALU-bound what counts is how full a round is, i.e. how many samples per lane it
-// holds, and LDS bounds that: 1024 threads x 5 samples 4.33 | 768 x 7 4.24 | 512 x 12 (2 waves/SIMD, 256 VGPRs, no scratch;
-// march budget 512) 4.05 | 512 x 10 4.57 | 512 x 8 4.25.
-#ifndef RV_S
-#define RV_S 12                        // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
-#endif
-#ifndef RV_BLOCK_THREADS
-#define RV_BLOCK_THREADS 512
-#endif
-#ifndef RV_BLOCKS_PER_CU
-#define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // the sample slots (96 KiB at 512 x 12) only fit beside ONE copy of the weights per CU
-#endif
-#ifndef RV_PIPELINE
-#define RV_PIPELINE 0                  // 1: issue the next tile's hashed-level gathers before the current tile's MLP (software
-#endif                                 // pipeline across tiles).  A/B on MI355X: 5.0-5.2 ms with, 4.8-5.0 ms without: four waves per
-                                       // SIMD already overlap gather and MLP phases; the texture path is throughput-, not latency-
-                                       // bound, and the tile list / extra shuffles cost VALU.  Off.
 #ifndef RV_TILE_ORDER
 #define RV_TILE_ORDER 0                // 1: hand out the 8x8 pixel tiles most expensive first (k_tile_estimate / k_tile_order).
 #endif                                 // A/B on MI355X: 5.25-5.35 ms with, 5.0-5.2 ms without: the frame is bound by L1 tag and
@@ -1546,46 +1099,48 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         RV_TICK(c_march)
         // ---- field evaluation: for each group of 16 rays, tile k = their k-th samples ----
 #if RV_PIPELINE
+        static_assert(RV_S <= 4, "the tile list of RV_PIPELINE packs k in two bits");
         {
-            // Software pipeline across tiles: ALL gathers of the next tile are issued before the MLP of the current one, so a
-            // wave keeps the texture path busy while it sits in its 36-MFMA chain (two waves per SIMD do not overlap the
-            // phases by themselves).  Costs 47 registers across the MLP (32 rows, 12 fractions, the position).
-            // kmax[p] = most samples any ray of lane group p holds: tile (p, k) exists for k < kmax[p]
-            int km = cnt;
+            // Software pipeline across tiles: the gathers of the hashed half of the NEXT tile (levels 8+g, 12+g: the slow
+            // ones) are issued before the MLP of the current tile, so a wave keeps the texture path busy while it sits in
+            // its 36-MFMA chain.  Costs 25 registers across the MLP (16 rows, 6 fractions, the next position).
+            unsigned long long list = 0ull;            // the round's tiles, 4 bits each: (p << 2) | k
+            int T = 0;
             #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const int o = __shfl_xor(km, off, 64);
-                km = o > km ? o : km;
+            for (int p = 0; p < 4; p++) {
+                const int cc = __shfl(cnt, 16 * p + s, 64);
+                #pragma unroll
+                for (int k = 0; k < RV_S; k++)
+                    if (__ballot(cc > k) != 0ull) { list |= (unsigned long long)(p * 4 + k) << (4 * T); T++; }
             }
-            int kmax[4];
-            #pragma unroll
-            for (int p = 0; p < 4; p++) kmax[p] = __builtin_amdgcn_readlane(km, 16 * p);
-            auto first_group = [&](int p) { while (p < 4 && kmax[p < 4 ? p : 3] == 0) p++; return p; };
             const rf_lane_levels lv = lds_lv[g];
-            rf_pair na, nb;                            // rows of the tile in flight
-            int p = first_group(0), k = 0;
-            auto issue = [&](int pp, int kk) {
-                const int src = 16 * pp + s;
-                float4 q = wave_smp[src * RV_S + kk];
-                if (!(__shfl(cnt, src, 64) > kk)) q = make_float4(0.f, 0.f, 0.f, 0.f);
-                float x0, x1, x2;
+            rf_pair nxt;
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;        // normalised position of the tile whose pair 1 is in flight
+            if (T > 0) {
+                const int code = (int)(list & 15ull), src = 16 * (code >> 2) + s, k = code & 3;
+                float4 q = wave_smp[src * RV_S + k];
+                if (!(__shfl(cnt, src, 64) > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);
                 rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
-                rf_gather_pair<0>(P, lv, cls, x0, x1, x2, na);
-                rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nb);
-            };
-            if (p < 4) issue(p, 0);
+                rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nxt);
+            }
             #pragma unroll 1
-            while (p < 4) {
-                const int src = 16 * p + s;
+            for (int n = 0; n < T; n++) {
+                const int code = (int)((list >> (4 * n)) & 15ull), src = 16 * (code >> 2) + s, k = code & 3;
                 const bool valid = __shfl(cnt, src, 64) > k;
                 const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
                 n_tiles++;
+                rf_pair cur;
+                rf_gather_pair<0>(P, lv, cls, x0, x1, x2, cur);
                 ngp_h8 x;
-                rf_blend_pair(na, 0, x);
-                rf_blend_pair(nb, 1, x);
-                int p1 = p, k1 = k + 1;                // the next tile
-                if (k1 >= kmax[p]) { p1 = first_group(p + 1); k1 = 0; }
-                if (p1 < 4) issue(p1, k1);
+                rf_blend_pair(cur, 0, x);
+                rf_blend_pair(nxt, 1, x);
+                if (n + 1 < T) {
+                    const int code1 = (int)((list >> (4 * (n + 1))) & 15ull), src1 = 16 * (code1 >> 2) + s, k1 = code1 & 3;
+                    float4 q = wave_smp[src1 * RV_S + k1];
+                    if (!(__shfl(cnt, src1, 64) > k1)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
+                    rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nxt);
+                }
                 __builtin_amdgcn_sched_barrier(0);       // the prefetch stays above the MLP
                 float a, b, c, d;
                 rv_mlp_tile(lds_w, lane, x, shq, a, b, c, d);
@@ -1594,7 +1149,6 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                     r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
                     *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k]) = r;
                 }
-                p = p1; k = k1;
             }
         }
 #else
