@@ -1099,48 +1099,46 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         RV_TICK(c_march)
         // ---- field evaluation: for each group of 16 rays, tile k = their k-th samples ----
 #if RV_PIPELINE
-        static_assert(RV_S <= 4, "the tile list of RV_PIPELINE packs k in two bits");
         {
-            // Software pipeline across tiles: the gathers of the hashed half of the NEXT tile (levels 8+g, 12+g: the slow
-            // ones) are issued before the MLP of the current tile, so a wave keeps the texture path busy while it sits in
-            // its 36-MFMA chain.  Costs 25 registers across the MLP (16 rows, 6 fractions, the next position).
-            unsigned long long list = 0ull;            // the round's tiles, 4 bits each: (p << 2) | k
-            int T = 0;
+            // Software pipeline across tiles: ALL gathers of the next tile are issued before the MLP of the current one, so a
+            // wave keeps the texture path busy while it sits in its 36-MFMA chain (two waves per SIMD do not overlap the
+            // phases by themselves).  Costs 47 registers across the MLP (32 rows, 12 fractions, the position).
+            // kmax[p] = most samples any ray of lane group p holds: tile (p, k) exists for k < kmax[p]
+            int km = cnt;
             #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const int cc = __shfl(cnt, 16 * p + s, 64);
-                #pragma unroll
-                for (int k = 0; k < RV_S; k++)
-                    if (__ballot(cc > k) != 0ull) { list |= (unsigned long long)(p * 4 + k) << (4 * T); T++; }
+            for (int off = 1; off < 16; off <<= 1) {
+                const int o = __shfl_xor(km, off, 64);
+                km = o > km ? o : km;
             }
+            int kmax[4];
+            #pragma unroll
+            for (int p = 0; p < 4; p++) kmax[p] = __builtin_amdgcn_readlane(km, 16 * p);
+            auto first_group = [&](int p) { while (p < 4 && kmax[p < 4 ? p : 3] == 0) p++; return p; };
             const rf_lane_levels lv = lds_lv[g];
-            rf_pair nxt;
-            float x0 = 0.f, x1 = 0.f, x2 = 0.f;        // normalised position of the tile whose pair 1 is in flight
-            if (T > 0) {
-                const int code = (int)(list & 15ull), src = 16 * (code >> 2) + s, k = code & 3;
-                float4 q = wave_smp[src * RV_S + k];
-                if (!(__shfl(cnt, src, 64) > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+            rf_pair na, nb;                            // rows of the tile in flight
+            int p = first_group(0), k = 0;
+            auto issue = [&](int pp, int kk) {
+                const int src = 16 * pp + s;
+                float4 q = wave_smp[src * RV_S + kk];
+                if (!(__shfl(cnt, src, 64) > kk)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                float x0, x1, x2;
                 rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
-                rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nxt);
-            }
+                rf_gather_pair<0>(P, lv, cls, x0, x1, x2, na);
+                rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nb);
+            };
+            if (p < 4) issue(p, 0);
             #pragma unroll 1
-            for (int n = 0; n < T; n++) {
-                const int code = (int)((list >> (4 * n)) & 15ull), src = 16 * (code >> 2) + s, k = code & 3;
+            while (p < 4) {
+                const int src = 16 * p + s;
                 const bool valid = __shfl(cnt, src, 64) > k;
                 const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
                 n_tiles++;
-                rf_pair cur;
-                rf_gather_pair<0>(P, lv, cls, x0, x1, x2, cur);
                 ngp_h8 x;
-                rf_blend_pair(cur, 0, x);
-                rf_blend_pair(nxt, 1, x);
-                if (n + 1 < T) {
-                    const int code1 = (int)((list >> (4 * (n + 1))) & 15ull), src1 = 16 * (code1 >> 2) + s, k1 = code1 & 3;
-                    float4 q = wave_smp[src1 * RV_S + k1];
-                    if (!(__shfl(cnt, src1, 64) > k1)) q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    rf_normalise(P, q.x, q.y, q.z, x0, x1, x2);
-                    rf_gather_pair<1>(P, lv, cls, x0, x1, x2, nxt);
-                }
+                rf_blend_pair(na, 0, x);
+                rf_blend_pair(nb, 1, x);
+                int p1 = p, k1 = k + 1;                // the next tile
+                if (k1 >= kmax[p]) { p1 = first_group(p + 1); k1 = 0; }
+                if (p1 < 4) issue(p1, k1);
                 __builtin_amdgcn_sched_barrier(0);       // the prefetch stays above the MLP
                 float a, b, c, d;
                 rv_mlp_tile(lds_w, lane, x, shq, a, b, c, d);
@@ -1149,6 +1147,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                     r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
                     *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k]) = r;
                 }
+                p = p1; k = k1;
             }
         }
 #else
