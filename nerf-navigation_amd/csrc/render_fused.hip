@@ -469,6 +469,9 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_BLOCKS_PER_CU
 #define RV_BLOCKS_PER_CU (RV_S > 1 ? 1 : 2)   // the sample slots (96 KiB at 512 x 12) only fit beside ONE copy of the weights per CU
 #endif
+#ifndef RV_TILE_PAIRS
+#define RV_TILE_PAIRS 1                // evaluate tiles k and k+1 of a lane group together: two MFMA chains per pass
+#endif
 #ifndef RV_PIPELINE
 #define RV_PIPELINE 0                  // 1: issue the next tile's gathers before the current tile's MLP (software pipeline across
 #endif                                 // tiles).  A/B on MI355X: at 4 waves/SIMD (hashed half prefetched) 5.0-5.2 vs 4.8-5.0 ms; at
@@ -633,58 +636,98 @@ __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_
     rv_mlp_tile(lds_w, lane, x, shq, sigma, cr, cg, cb);
 }
 
-// The two networks on one 16-column tile whose encoded features are already in B-fragment layout (weights from LDS).
-__device__ __forceinline__ void rv_mlp_tile(const ngp_h8* __restrict__ lds_w, int lane, const ngp_h8 x, ngp_h4 shq,
-                                            float& sigma, float& cr, float& cg, float& cb) {
+// The two networks on NT 16-column tiles at once (encoded features already in B-fragment layout, weights from LDS).  NT = 2
+// runs two independent MFMA chains through every layer: each weight fragment is read from LDS once for both tiles and the
+// second chain fills the issue slots the first one leaves while it waits on its MFMA results (with two waves per SIMD there
+// is little else to fill them).
+template <int NT>
+__device__ __forceinline__ void rv_mlp_tiles(const ngp_h8* __restrict__ lds_w, int lane, const ngp_h8 (&x)[NT], const ngp_h4 (&shq)[NT],
+                                             float (&sigma)[NT], float (&cr)[NT], float (&cg)[NT], float (&cb)[NT]) {
     const ngp_f4 zero = {0.f, 0.f, 0.f, 0.f};
-    ngp_h8 act[2];
+    ngp_h8 act[NT][2];
     {
-        ngp_f4 d[MLP_MT];
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(rv_frag(lds_w, t, lane), x, zero);
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
-    }
-    {
-        ngp_f4 d[MLP_MT];
+        ngp_f4 d[NT][MLP_MT];
         #pragma unroll
         for (int t = 0; t < MLP_MT; t++) {
-            d[t] = ngp_mfma(rv_frag(lds_w, 4 + 2 * t, lane), act[0], zero);
-            d[t] = ngp_mfma(rv_frag(lds_w, 5 + 2 * t, lane), act[1], d[t]);
+            const ngp_h8 w = rv_frag(lds_w, t, lane);
+            #pragma unroll
+            for (int n = 0; n < NT; n++) d[n][t] = ngp_mfma(w, x[n], zero);
         }
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
-    }
-    ngp_f4 h = ngp_mfma(rv_frag(lds_w, 12, lane), act[0], zero);
-    h = ngp_mfma(rv_frag(lds_w, 13, lane), act[1], h);
-
-    ngp_h8 cin;
-    #pragma unroll
-    for (int j = 0; j < 4; j++) { cin[j] = (_Float16)h[j]; cin[4 + j] = shq[j]; }
-    {
-        ngp_f4 d[MLP_MT];
         #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(rv_frag(lds_w, 14 + t, lane), cin, zero);
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
+        for (int n = 0; n < NT; n++) { act[n][0] = mlp_pack_relu(d[n][0], d[n][1]); act[n][1] = mlp_pack_relu(d[n][2], d[n][3]); }
+    }
+    {
+        ngp_f4 d[NT][MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) {
+            const ngp_h8 w0 = rv_frag(lds_w, 4 + 2 * t, lane), w1 = rv_frag(lds_w, 5 + 2 * t, lane);
+            #pragma unroll
+            for (int n = 0; n < NT; n++) d[n][t] = ngp_mfma(w0, act[n][0], zero);
+            #pragma unroll
+            for (int n = 0; n < NT; n++) d[n][t] = ngp_mfma(w1, act[n][1], d[n][t]);
+        }
+        #pragma unroll
+        for (int n = 0; n < NT; n++) { act[n][0] = mlp_pack_relu(d[n][0], d[n][1]); act[n][1] = mlp_pack_relu(d[n][2], d[n][3]); }
+    }
+    ngp_f4 h[NT];
+    {
+        const ngp_h8 w0 = rv_frag(lds_w, 12, lane), w1 = rv_frag(lds_w, 13, lane);
+        #pragma unroll
+        for (int n = 0; n < NT; n++) h[n] = ngp_mfma(w0, act[n][0], zero);
+        #pragma unroll
+        for (int n = 0; n < NT; n++) h[n] = ngp_mfma(w1, act[n][1], h[n]);
+    }
+    ngp_h8 cin[NT];
+    #pragma unroll
+    for (int n = 0; n < NT; n++)
+        #pragma unroll
+        for (int j = 0; j < 4; j++) { cin[n][j] = (_Float16)h[n][j]; cin[n][4 + j] = shq[n][j]; }
+    {
+        ngp_f4 d[NT][MLP_MT];
+        #pragma unroll
+        for (int t = 0; t < MLP_MT; t++) {
+            const ngp_h8 w = rv_frag(lds_w, 14 + t, lane);
+            #pragma unroll
+            for (int n = 0; n < NT; n++) d[n][t] = ngp_mfma(w, cin[n], zero);
+        }
+        #pragma unroll
+        for (int n = 0; n < NT; n++) { act[n][0] = mlp_pack_relu(d[n][0], d[n][1]); act[n][1] = mlp_pack_relu(d[n][2], d[n][3]); }
     }
     #pragma unroll
     for (int l = 0; l < 2; l++) {
-        ngp_f4 d[MLP_MT];
+        ngp_f4 d[NT][MLP_MT];
         #pragma unroll
         for (int t = 0; t < MLP_MT; t++) {
-            d[t] = ngp_mfma(rv_frag(lds_w, 18 + 8 * l + 2 * t, lane), act[0], zero);
-            d[t] = ngp_mfma(rv_frag(lds_w, 19 + 8 * l + 2 * t, lane), act[1], d[t]);
+            const ngp_h8 w0 = rv_frag(lds_w, 18 + 8 * l + 2 * t, lane), w1 = rv_frag(lds_w, 19 + 8 * l + 2 * t, lane);
+            #pragma unroll
+            for (int n = 0; n < NT; n++) d[n][t] = ngp_mfma(w0, act[n][0], zero);
+            #pragma unroll
+            for (int n = 0; n < NT; n++) d[n][t] = ngp_mfma(w1, act[n][1], d[n][t]);
         }
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
+        #pragma unroll
+        for (int n = 0; n < NT; n++) { act[n][0] = mlp_pack_relu(d[n][0], d[n][1]); act[n][1] = mlp_pack_relu(d[n][2], d[n][3]); }
     }
-    ngp_f4 o = ngp_mfma(rv_frag(lds_w, 34, lane), act[0], zero);
-    o = ngp_mfma(rv_frag(lds_w, 35, lane), act[1], o);
+    {
+        const ngp_h8 w0 = rv_frag(lds_w, 34, lane), w1 = rv_frag(lds_w, 35, lane);
+        ngp_f4 o[NT];
+        #pragma unroll
+        for (int n = 0; n < NT; n++) o[n] = ngp_mfma(w0, act[n][0], zero);
+        #pragma unroll
+        for (int n = 0; n < NT; n++) o[n] = ngp_mfma(w1, act[n][1], o[n]);
+        // raw network outputs (lanes g == 0: density logit and the three colour logits of column s); the activations are
+        // applied once per round by the lane that owns the sample (rv_activate), not once per pass by all 64 lanes
+        #pragma unroll
+        for (int n = 0; n < NT; n++) { sigma[n] = h[n][0]; cr[n] = o[n][0]; cg[n] = o[n][1]; cb[n] = o[n][2]; }
+    }
+}
 
-    // raw network outputs (lanes g == 0: density logit and the three colour logits of column s); the activations are
-    // applied once per round by the lane that owns the sample (rv_activate), not once per pass by all 64 lanes
-    sigma = h[0]; cr = o[0]; cg = o[1]; cb = o[2];
+__device__ __forceinline__ void rv_mlp_tile(const ngp_h8* __restrict__ lds_w, int lane, const ngp_h8 x, ngp_h4 shq,
+                                            float& sigma, float& cr, float& cg, float& cb) {
+    const ngp_h8 xs[1] = {x};
+    const ngp_h4 ss[1] = {shq};
+    float a[1], b[1], c[1], d[1];
+    rv_mlp_tiles<1>(lds_w, lane, xs, ss, a, b, c, d);
+    sigma = a[0]; cr = b[0]; cg = c[0]; cb = d[0];
 }
 
 // trunc_exp forward (activation.py:9-10, fp32 of the half logit) times density_scale, and torch.sigmoid on the half logits
@@ -1158,6 +1201,44 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             if (__ballot(ccol > 0) == 0ull) continue;
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
             const rf_lane_levels lv = lds_lv[g];
+#if RV_TILE_PAIRS
+            // tiles k and k+1 of the group together (the same 16 rays, consecutive samples): two MFMA chains per pass
+            #pragma unroll 1
+            for (int k = 0; k < RV_S; k += 2) {
+                if (__ballot(ccol > k) == 0ull) break;   // counts only shrink with k
+                if (k + 1 < RV_S && __ballot(ccol > k + 1) != 0ull) {
+                    ngp_h8 xs[2];
+                    #pragma unroll
+                    for (int n = 0; n < 2; n++) {
+                        float4 q = wave_smp[src * RV_S + k + n];
+                        if (!(ccol > k + n)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                        xs[n] = rf_encode<true>(P, lv, cls, q.x, q.y, q.z);
+                    }
+                    n_tiles += 2;
+                    const ngp_h4 ss[2] = {shq, shq};
+                    float a[2], b[2], c[2], d[2];
+                    rv_mlp_tiles<2>(lds_w, lane, xs, ss, a, b, c, d);
+                    #pragma unroll
+                    for (int n = 0; n < 2; n++)
+                        if (g == 0 && ccol > k + n) {
+                            ngp_h4 r;
+                            r[0] = (_Float16)a[n]; r[1] = (_Float16)b[n]; r[2] = (_Float16)c[n]; r[3] = (_Float16)d[n];
+                            *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k + n]) = r;
+                        }
+                } else {
+                    float4 q = wave_smp[src * RV_S + k];
+                    if (!(ccol > k)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    n_tiles++;
+                    float a, b, c, d;
+                    rv_field_tile(P, lv, cls, lds_w, lane, q.x, q.y, q.z, shq, a, b, c, d);
+                    if (g == 0 && ccol > k) {
+                        ngp_h4 r;
+                        r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
+                        *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k]) = r;
+                    }
+                }
+            }
+#else
             #pragma unroll 1
             for (int k = 0; k < RV_S; k++) {
                 if (__ballot(ccol > k) == 0ull) break;   // counts only shrink with k
@@ -1172,6 +1253,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                     *reinterpret_cast<ngp_h4*>(&wave_smp[src * RV_S + k]) = r;
                 }
             }
+#endif
         }
 #endif
 
