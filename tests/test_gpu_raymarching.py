@@ -245,3 +245,26 @@ def test_empty_inputs(dev):
     assert n.shape == (0,) and f.shape == (0,)
     out, cnt = raymarching.compact_alive(torch.full((5,), -1, dtype=torch.int32, device=dev))
     assert int(cnt.item()) == 0
+
+
+@pytest.mark.parametrize("bound,cas,grid_h,dt_gamma", [(1.0, 1, 64, 0.0), (4.0, 3, 64, 1.0 / 256), (2.0, 2, 32, 0.0), (1.5, 2, 128, 0.0),
+                                                         (2.0, 2, 128, 1.0 / 64)])
+def test_march_to_completion_on_other_grids(oracle, dev, bound, cas, grid_h, dt_gamma):
+    """march_rays_train with force_all_rays = every sample of every ray.  Grids on which the kernels skip empty blocks (H >= 64,
+    power-of-two bound or one cascade) and grids on which they must not (H = 32; bound 1.5), sparse scenes with long empty
+    stretches: sample positions, steps and per-ray counts bit-exact against the oracle, which marches cell by cell."""
+    import raymarching
+    bf, _ = blob_bitfield(oracle, cas, grid_h, seed=5, n_blobs=6, bound=bound)       # few blobs: mostly empty space
+    o, d = camera_rays(40, radius=1.6 * bound, seed=9)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    ref = oracle.march_rays_train(o, d, bound, bf, cas, grid_h, nears, fars, force_all_rays=True, dt_gamma=dt_gamma, max_steps=1024)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    x, dd, l, rays = raymarching.march_rays_train(t(o, dev), t(d, dev), bound, t(bf, dev), cas, grid_h, t(nears, dev), t(fars, dev),
+                                                  counter, -1, False, 128, True, dt_gamma, 1024)
+    x_ref, d_ref, l_ref, r_ref = ref[0], ref[1], ref[2], ref[3]
+    total = int(counter[0].item())
+    assert total == int(r_ref[:, 2].sum()) and total > 2000
+    assert_same_bits(rays, r_ref, "rays")
+    assert_same_bits(l[:total], l_ref[:total], "deltas")
+    assert_same_bits(x[:total], x_ref[:total], "xyzs")
