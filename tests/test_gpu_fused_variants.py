@@ -125,3 +125,26 @@ def test_three_cascades_without_the_lds_map(oracle, dev):
     stats = out["stats"].cpu().numpy()
     assert abs(int(stats[0]) - ref["samples"]) <= max(8, 2e-3 * ref["samples"]) and stats[0] > 1000
     assert np.max(np.abs(out["image"][0].cpu().numpy() - ref["image"])) < 8e-3
+
+
+@pytest.mark.parametrize("grid_h", [64, 32])
+def test_other_grid_sizes(oracle, dev, grid_h):
+    """density grids of 64^3 (block skipping still allowed) and 32^3 (coarse map, no skipping) in a sparse scene"""
+    from _util import blob_bitfield, camera_rays
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    bound = 2.0
+    model = W.make_model(3, bound=bound)
+    field = NGPFieldFF(bound=bound).to(dev).load_arrays(model)
+    ren = NGPRenderer(field, bound=bound, cuda_ray=True, density_thresh=0.5, grid_size=grid_h).to(dev).eval()
+    bitfield, grid = blob_bitfield(oracle, 2, grid_h, seed=8, n_blobs=8, bound=bound)
+    ren.load_density_grid(grid)
+    assert np.array_equal(ren.density_bitfield.cpu().numpy(), bitfield)
+    o, d = camera_rays(32, radius=3.0, seed=6)
+    ref = R.render_single_march(lambda x, dd: R.field_forward(model, x, dd, 1.0), o, d, bitfield, bound, 2, H=grid_h)
+    out = ren.render_fused(t(o, dev)[None], t(d, dev)[None], bg_color=1)
+    stats = out["stats"].cpu().numpy()
+    assert abs(int(stats[0]) - ref["samples"]) <= max(8, 2e-3 * ref["samples"]) and stats[0] > 500
+    assert stats[2] == int((ref["consumed"] > 0).sum())
+    assert np.max(np.abs(out["image"][0].cpu().numpy() - ref["image"])) < 8e-3
