@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--cpu-res", type=int, default=144, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--path", default="fused", choices=["fused", "per_op"], help="per_op = the reference-shaped op-by-op loop")
+    ap.add_argument("--path", default="fused", choices=["fused", "per_op", "per_op_fused_field"], help="per_op = the reference-shaped op-by-op loop")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render = the headline metric; train = secondary: training steps (configs 3 / 5), 4096 rays per step per GPU")
     args = ap.parse_args()
@@ -144,7 +144,8 @@ def main():
         if args.path == "fused":
             return ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024)
+            return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024,
+                                fused_field=(args.path == "per_op_fused_field"))
 
     def sync_all():
         torch.cuda.synchronize()

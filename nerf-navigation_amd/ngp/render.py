@@ -66,7 +66,7 @@ class NGPRenderer(nn.Module):
     # occupancy-grid path, op by op
     # ------------------------------------------------------------------------------------------------------------
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
-                 trace=None, **kwargs):
+                 trace=None, fused_field=False, **kwargs):
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -106,8 +106,13 @@ class NGPRenderer(nn.Module):
                 xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
                                                             self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                                                             128, perturb, dt_gamma, max_steps)
-                sigmas, rgbs = self(xyzs, dirs)
-                sigmas = self.density_scale * sigmas
+                if fused_field:
+                    # the reference's loop and schedule, but encoder + both MLPs + activations in ONE launch per iteration
+                    # (ngp_field_forward: sigma already times the field's density_scale) instead of ~25 small ones
+                    sigmas, rgbs = self.field.forward_fused(xyzs, dirs)
+                else:
+                    sigmas, rgbs = self(xyzs, dirs)
+                    sigmas = self.density_scale * sigmas
                 raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
                 if trace is not None:
                     trace.append((n_alive, n_step, int((deltas[:, 0] > 0).sum().item())))

@@ -139,3 +139,19 @@ def test_render_fused_empty_and_missing_rays(setup, dev):
     assert torch.isnan(out["depth"]).all()                             # 0/0, exactly like nerf/renderer.py:372
     out = ren.render_fused(o[None, :0], d[None, :0], bg_color=1)
     assert out["image"].shape == (1, 0, 3)
+
+
+def test_run_cuda_with_fused_field_matches_the_per_op_loop(setup, dev):
+    """run_cuda(fused_field=True): the reference's loop and schedule with one field launch per iteration.  Same alive-set
+    schedule (the trace), same image up to the exp / sigmoid rounding of the two field implementations."""
+    ren, W = setup["ren"], setup["W"]
+    o, d = W.get_rays(W.orbit_pose(4), W.intrinsics(HW, HW), HW, HW)
+    o, d = t(o, dev)[None], t(d, dev)[None]
+    ta, tb = [], []
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = ren.run_cuda(o, d, bg_color=1, trace=ta)
+        b = ren.run_cuda(o, d, bg_color=1, trace=tb, fused_field=True)
+    assert [x[:2] for x in ta[:20]] == [x[:2] for x in tb[:20]]                       # the first iterations: identical schedule
+    assert abs(sum(x[2] for x in ta) - sum(x[2] for x in tb)) <= max(8, 2e-4 * sum(x[2] for x in ta))
+    assert float((a["image"] - b["image"]).abs().max()) < 2e-3
+    assert float((a["depth"] - b["depth"]).abs().max()) < 2e-3
