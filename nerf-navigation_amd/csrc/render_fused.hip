@@ -299,107 +299,8 @@ __device__ __forceinline__ ngp_h8 rf_load_a_color_in(const _Float16* __restrict_
     return a;
 }
 
-struct rf_weights {
-    mlp_weights<1, 1> sig;                             // FFMLP(32 -> 64 -> 64 -> 16), num_layers 2
-    ngp_h8 c_in[MLP_MT];
-    ngp_h8 c_hid[2][MLP_MT][2];                        // FFMLP(32 -> 64 -> 64 -> 64 -> 16), num_layers 3
-    ngp_h8 c_out[2];
-    __device__ __forceinline__ void load(const rf_params& P, int lane) {
-        sig.load(P.w_sigma, 32, lane);
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) sig.w_in[t][0] = rf_load_a_sigma_in(P.w_sigma, t, lane);
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) c_in[t] = rf_load_a_color_in(P.w_color, t, lane);
-        const _Float16* Wh = P.w_color + MLP_W * 32;
-        #pragma unroll
-        for (int h = 0; h < 2; h++)
-            #pragma unroll
-            for (int t = 0; t < MLP_MT; t++)
-                #pragma unroll
-                for (int c = 0; c < 2; c++) c_hid[h][t][c] = mlp_load_a_permuted(Wh + h * MLP_W * MLP_W, MLP_W, t, c, lane);
-        #pragma unroll
-        for (int c = 0; c < 2; c++) c_out[c] = mlp_load_a_permuted(Wh + 2 * MLP_W * MLP_W, MLP_W, 0, c, lane);
-    }
-};
-
-// One 16-column tile: (world position, direction) of column s's sample, held redundantly by its 4 lanes.
-// Returns, valid in lanes g == 0: sigma (already times density_scale) and rgb.
-__device__ __forceinline__ void rf_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls, const rf_weights& W, int g,
-                                              float px, float py, float pz, float dx, float dy, float dz,
-                                              float& sigma, float& cr, float& cg, float& cb) {
-    ngp_h8 x[1];
-    x[0] = rf_encode(P, lv, cls, px, py, pz);
-    const ngp_f4 h = mlp_forward_tile<1, 1>(W.sig, x, [](int, const ngp_h8 (&)[2]) {});
-
-    float sh[16];
-    sh_eval<4>(dx, dy, dz, P.shn, sh);
-    ngp_h8 cin;
-    #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        cin[j] = (_Float16)h[j];                       // density-net output, rounded to half (FFMLP output dtype)
-        float s = sh[j];
-        if (g == 1) s = sh[4 + j];
-        if (g == 2) s = sh[8 + j];
-        if (g == 3) s = sh[12 + j];
-        cin[4 + j] = (_Float16)s;                      // cat(...) enters FFMLP through cast_inputs=half
-    }
-    ngp_h8 act[2];
-    {
-        ngp_f4 d[MLP_MT];
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) d[t] = ngp_mfma(W.c_in[t], cin, ngp_f4{0.f, 0.f, 0.f, 0.f});
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
-    }
-    #pragma unroll
-    for (int l = 0; l < 2; l++) {
-        ngp_f4 d[MLP_MT];
-        #pragma unroll
-        for (int t = 0; t < MLP_MT; t++) {
-            d[t] = ngp_mfma(W.c_hid[l][t][0], act[0], ngp_f4{0.f, 0.f, 0.f, 0.f});
-            d[t] = ngp_mfma(W.c_hid[l][t][1], act[1], d[t]);
-        }
-        act[0] = mlp_pack_relu(d[0], d[1]);
-        act[1] = mlp_pack_relu(d[2], d[3]);
-    }
-    ngp_f4 o = ngp_mfma(W.c_out[0], act[0], ngp_f4{0.f, 0.f, 0.f, 0.f});
-    o = ngp_mfma(W.c_out[1], act[1], o);
-
-    // lanes g == 0 hold h0 (row 0 of the density tile) and rows 0..2 of the colour tile
-    sigma = P.density_scale * ngp_expf(rf_h(h[0]));                                   // trunc_exp forward (activation.py:9-10), fp32
-    cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[0]))));                                 // torch.sigmoid on a half tensor
-    cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[1]))));
-    cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(o[2]))));
-}
-
-// ---------------------------------------------------------------------------
-// field_forward: sigma / rgb for explicit points
-// ---------------------------------------------------------------------------
-
-__global__ __launch_bounds__(RF_BLOCK) void k_field_forward(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
-                                                            uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
-    const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
-    rf_lane_levels lv;
-    rf_setup_levels(P, g, lv);
-    const rf_iter_class cls = rf_classify(lv);
-    rf_weights W;
-    W.load(P, lane);
-    const uint32_t ntiles = (M + 15) >> 4;
-    for (uint32_t tile = wave; tile < ntiles; tile += nwaves) {
-        const uint32_t m = tile * 16 + s;
-        const bool valid = m < M;
-        const uint64_t mm = valid ? m : 0;
-        const float px = xyzs[3 * mm], py = xyzs[3 * mm + 1], pz = xyzs[3 * mm + 2];
-        const float dx = dirs[3 * mm], dy = dirs[3 * mm + 1], dz = dirs[3 * mm + 2];
-        float sigma, cr, cg, cb;
-        rf_field_tile(P, lv, cls, W, g, px, py, pz, dx, dy, dz, sigma, cr, cg, cb);
-        if (g == 0 && valid) {
-            sigmas[m] = sigma;
-            rgbs[3ull * m] = cr; rgbs[3ull * m + 1] = cg; rgbs[3ull * m + 2] = cb;
-        }
-    }
-}
+__global__ void k_field_forward_lds(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
+                                    float* __restrict__ sigmas, float* __restrict__ rgbs);
 
 static int rf_fill_params(const char* who, const ngp_field_t* f, rf_params& P) {
     NGP_REQUIRE(f && f->embeddings && f->offsets && f->sigma_weights && f->color_weights, "%s: null field pointer", who);
@@ -431,10 +332,10 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
     if (rc != NGP_OK) return rc;
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && dirs && sigmas && rgbs, "field_forward: null pointer");
-    const uint32_t ntiles = (M + 15) >> 4;
-    uint32_t blocks = ngp_div_up(ntiles, 4 * 4);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_field_forward, dim3(blocks), dim3(RF_BLOCK), 0, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs);
+    const uint32_t npairs = (M + 31) >> 5;
+    uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
+    if (blocks > 256 * 4) blocks = 256 * 4;            // four 36-KiB workgroups per CU
+    hipLaunchKernelGGL(k_field_forward_lds, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs);
     NGP_CHECK_LAUNCH("field_forward");
     return NGP_OK;
 }
@@ -627,7 +528,7 @@ __device__ __forceinline__ ngp_h8 rv_frag(const ngp_h8* __restrict__ lds_w, int 
 __device__ __forceinline__ void rv_mlp_tile(const ngp_h8* __restrict__ lds_w, int lane, const ngp_h8 x, ngp_h4 shq,
                                             float& sigma, float& cr, float& cg, float& cb);
 
-// rf_field_tile with the weights streamed from LDS and the SH coefficients of the column's ray read from LDS
+// One tile of the field: encoder, then both networks with the weights streamed from LDS; the SH coefficients of the column's ray come from LDS
 __device__ __forceinline__ void rv_field_tile(const rf_params& P, const rf_lane_levels& lv, const rf_iter_class cls,
                                               const ngp_h8* __restrict__ lds_w, int lane,
                                               float px, float py, float pz, ngp_h4 shq,
@@ -730,12 +631,88 @@ __device__ __forceinline__ void rv_mlp_tile(const ngp_h8* __restrict__ lds_w, in
     sigma = a[0]; cr = b[0]; cg = c[0]; cb = d[0];
 }
 
+// The 36 MFMA weight fragments of both networks into LDS, each in the k order its consumer expects (fragment-major:
+// lane l reads 16 B at 16 l, a conflict-free ds_read_b128).
+__device__ __forceinline__ void rv_stage_weights(const rf_params& P, ngp_h8* __restrict__ lds_w, int wave, int nwaves, int lane) {
+    for (int f = wave; f < RV_NFRAG; f += nwaves) {
+        ngp_h8 a;
+        const _Float16* Wc = P.w_color;
+        const _Float16* Wch = Wc + MLP_W * 32;
+        if (f < 4) a = rf_load_a_sigma_in(P.w_sigma, f, lane);
+        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
+        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
+        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
+        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
+        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
+        lds_w[f * 64 + lane] = a;
+    }
+}
+
 // trunc_exp forward (activation.py:9-10, fp32 of the half logit) times density_scale, and torch.sigmoid on the half logits
 __device__ __forceinline__ void rv_activate(const rf_params& P, float& sigma, float& cr, float& cg, float& cb) {
     sigma = P.density_scale * ngp_expf(rf_h(sigma));
     cr = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(cr))));
     cg = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(cg))));
     cb = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(cb))));
+}
+
+// ---------------------------------------------------------------------------
+// field_forward for explicit points (NeRFNetwork.forward in one launch): the frame kernel's field step on its own.
+// 256-thread workgroups, weights in LDS (36 KiB, so four workgroups share a CU), two 16-point tiles per pass.
+// ---------------------------------------------------------------------------
+template <bool FIXED>
+__device__ __forceinline__ void rf_points_loop(const rf_params& P, const rf_iter_class cls_rt, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w,
+                                               const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
+                                               float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+    const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
+    const uint32_t npairs = (M + 31) >> 5;
+    for (uint32_t pair = wave; pair < npairs; pair += nwaves) {
+        ngp_h8 x[2];
+        ngp_h4 shq[2];
+        uint32_t m[2];
+        #pragma unroll
+        for (int n = 0; n < 2; n++) {
+            m[n] = pair * 32 + 16 * n + s;
+            const uint64_t mm = m[n] < M ? m[n] : 0;
+            const float px = xyzs[3 * mm], py = xyzs[3 * mm + 1], pz = xyzs[3 * mm + 2];
+            float sh[16];
+            sh_eval<4>(dirs[3 * mm], dirs[3 * mm + 1], dirs[3 * mm + 2], P.shn, sh);
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = sh[j];
+                if (g == 1) v = sh[4 + j];
+                if (g == 2) v = sh[8 + j];
+                if (g == 3) v = sh[12 + j];
+                shq[n][j] = (_Float16)v;               // cat(...) enters FFMLP through cast_inputs=half
+            }
+            x[n] = rf_encode<false>(P, lv, cls, px, py, pz);
+        }
+        float sg[2], cr[2], cg[2], cb[2];
+        rv_mlp_tiles<2>(lds_w, lane, x, shq, sg, cr, cg, cb);
+        #pragma unroll
+        for (int n = 0; n < 2; n++)
+            if (g == 0 && m[n] < M) {
+                rv_activate(P, sg[n], cr[n], cg[n], cb[n]);
+                sigmas[m[n]] = sg[n];
+                rgbs[3ull * m[n]] = cr[n]; rgbs[3ull * m[n] + 1] = cg[n]; rgbs[3ull * m[n] + 2] = cb[n];
+            }
+    }
+}
+
+__global__ __launch_bounds__(RF_BLOCK, 4) void k_field_forward_lds(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
+                                                                    uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
+    ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rf_smem);
+    const int lane = threadIdx.x & 63, g = lane >> 4, wave = threadIdx.x >> 6;
+    rv_stage_weights(P, lds_w, wave, RF_BLOCK / 64, lane);
+    rf_lane_levels lv;
+    rf_setup_levels(P, g, lv);
+    __syncthreads();
+    const rf_iter_class cls = rf_classify(lv);
+    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u) rf_points_loop<true>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs);
+    else rf_points_loop<false>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs);
 }
 
 // queue index -> ray id.  With tile_w set (rays are a row-major image whose width and height are multiples of 8)
@@ -767,18 +744,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
 
     // ---- stage the weight fragments (each in the k order its consumer expects) and the coarse map ----
-    for (int f = wave; f < RV_NFRAG; f += RV_WAVES) {
-        ngp_h8 a;
-        const _Float16* Wc = P.w_color;
-        const _Float16* Wch = Wc + MLP_W * 32;
-        if (f < 4) a = rf_load_a_sigma_in(P.w_sigma, f, lane);
-        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
-        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
-        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
-        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
-        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
-        lds_w[f * 64 + lane] = a;
-    }
+    rv_stage_weights(P, lds_w, wave, RV_WAVES, lane);
     if (lds_coarse) {
         const uint32_t nw = F.coarse_words * F.C;
         for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
@@ -1326,18 +1292,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
 
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
 
-    for (int f = wave; f < RV_NFRAG; f += RV_WAVES) {
-        ngp_h8 a;
-        const _Float16* Wc = P.w_color;
-        const _Float16* Wch = Wc + MLP_W * 32;
-        if (f < 4) a = rf_load_a_sigma_in(P.w_sigma, f, lane);
-        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
-        else if (f < 14) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
-        else if (f < 18) a = rf_load_a_color_in(Wc, f - 14, lane);
-        else if (f < 34) a = mlp_load_a_permuted(Wch + ((f - 18) >> 3) * MLP_W * MLP_W, MLP_W, ((f - 18) & 7) >> 1, (f - 18) & 1, lane);
-        else a = mlp_load_a_permuted(Wch + 2 * MLP_W * MLP_W, MLP_W, 0, f - 34, lane);
-        lds_w[f * 64 + lane] = a;
-    }
+    rv_stage_weights(P, lds_w, wave, RV_WAVES, lane);
     if (lds_coarse) {
         const uint32_t nw = F.coarse_words * F.C;
         for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
