@@ -74,6 +74,9 @@ int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
  * reference's atomics, raymarching.cu:409-410).
  * workspace: ngp_march_rays_train_workspace(N) bytes of scratch. */
 size_t ngp_march_rays_train_workspace(uint32_t N);
+/* Optional larger workspace (the above + N * max_steps floats): the count pass then records every sample's ray parameter and
+ * the second pass writes the samples from them, one lane per sample, instead of marching every ray a second time. */
+size_t ngp_march_rays_train_workspace_full(uint32_t N, uint32_t max_steps);
 int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                          const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,

@@ -193,7 +193,7 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* l
 
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a, int* __restrict__ rays,
                                                                 const int* __restrict__ counter,
-                                                                uint32_t* __restrict__ block_sums) {
+                                                                uint32_t* __restrict__ block_sums, float* __restrict__ tbuf) {
     __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
     const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     uint32_t num_steps = 0;
@@ -203,8 +203,12 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
         const float far = a.fars[n];
         m.allow_skip(a.C, a.H, far);
         float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
+        float* tb = tbuf ? tbuf + (size_t)n * a.max_steps : nullptr;
         while (t < far && num_steps < a.max_steps) {
-            if (m.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+            if (m.probe(t, x, y, z, dt)) {
+                if (tb) tb[num_steps] = t;                            // the sample's parameter: all the fill pass needs
+                num_steps++; t += dt;
+            }
         }
         const uint32_t slot = (uint32_t)counter[1] + n;
         if (slot < a.N) rays[3ull * slot + 2] = (int)num_steps;      // stash; the write pass completes the record
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 const uint32_t* __restrict__ bases,
                                                                 float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                                float* __restrict__ deltas) {
+                                                                float* __restrict__ deltas, int offsets_only) {
     __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
     const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     const uint32_t ray_base = bases[1];
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a
     const uint32_t point_index = block_sums[blockIdx.x] + inc - num_steps;
     rays[3ull * slot] = (int)n;
     rays[3ull * slot + 1] = (int)point_index;
+    if (offsets_only) return;                        // k_march_train_fill writes the samples from the recorded parameters
     if (num_steps == 0) return;
     if (point_index + num_steps >= a.M) return;      // dropped ray (reference :420)
 
@@ -284,8 +289,53 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a
     }
 }
 
+// Second pass when the count pass recorded every sample's t (workspace permitting): one 64-thread workgroup per ray, one
+// lane per sample.  Everything the march wrote follows from t alone with the march's own operations
+// (raymarching.cu:365-367,386-391): x = clamp(o + t d), dt = clamp(t dt_gamma, dt_min, dt_max), deltas = (dt, (t + dt) - last_t)
+// with last_t the previous sample's t + dt (the ray's start for the first).  No second march.
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_fill(march_args a, const int* __restrict__ rays, const uint32_t* __restrict__ bases,
+                                                               const float* __restrict__ tbuf, float* __restrict__ xyzs,
+                                                               float* __restrict__ dirs, float* __restrict__ deltas) {
+    const uint32_t n = blockIdx.x;
+    const uint32_t slot = bases[1] + n;
+    if (slot >= a.N) return;
+    const uint32_t point_index = (uint32_t)rays[3ull * slot + 1], num_steps = (uint32_t)rays[3ull * slot + 2];
+    if (num_steps == 0 || point_index + num_steps >= a.M) return;     // nothing to write / dropped ray (reference :420)
+    const float* o = a.rays_o + 3ull * n;
+    const float* d = a.rays_d + 3ull * n;
+    const float ox = o[0], oy = o[1], oz = o[2], dx = d[0], dy = d[1], dz = d[2];
+    const float dt_min = (2.0f * 1.7320508075688772f) / (float)a.max_steps;
+    const float dt_max = ((2.0f * 1.7320508075688772f) * (float)(1 << (a.C - 1))) / (float)a.H;
+    float t_start = a.nears[n];
+    if (a.perturb) {
+        ngp_pcg32 rng; rng.seed(42u);
+        rng.advance((uint64_t)n);
+        t_start = t_start + dt_min * rng.next_float();
+    }
+    const float* tb = tbuf + (size_t)n * a.max_steps;
+    for (uint32_t k = threadIdx.x; k < num_steps; k += RM_RAY_BLOCK) {
+        const float t = tb[k];
+        const float dt = ngp_clampf(t * a.dt_gamma, dt_min, dt_max);
+        float last_t = t_start;
+        if (k > 0) { const float tp = tb[k - 1]; last_t = tp + ngp_clampf(tp * a.dt_gamma, dt_min, dt_max); }
+        const uint64_t p = (uint64_t)point_index + k;
+        xyzs[3 * p] = ngp_clampf(ox + t * dx, -a.bound, a.bound);
+        xyzs[3 * p + 1] = ngp_clampf(oy + t * dy, -a.bound, a.bound);
+        xyzs[3 * p + 2] = ngp_clampf(oz + t * dz, -a.bound, a.bound);
+        dirs[3 * p] = dx; dirs[3 * p + 1] = dy; dirs[3 * p + 2] = dz;
+        deltas[2 * p] = dt;
+        deltas[2 * p + 1] = (t + dt) - last_t;
+    }
+}
+
 extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) {
     return sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4);
+}
+
+// The same plus room for every sample's t (N * max_steps floats): with it the second pass does not march again.
+extern "C" size_t ngp_march_rays_train_workspace_full(uint32_t N, uint32_t max_steps) {
+    const size_t base = (ngp_march_rays_train_workspace(N) + 255) & ~(size_t)255;
+    return base + sizeof(float) * (size_t)N * max_steps;
 }
 
 extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -303,9 +353,13 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
     uint32_t* bases = block_sums + nblocks;
     march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, N, C, H, M, perturb};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, counter, block_sums);
+    float* tbuf = nullptr;
+    if (workspace_bytes >= ngp_march_rays_train_workspace_full(N, max_steps))
+        tbuf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + ((ngp_march_rays_train_workspace(N) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, counter, block_sums, tbuf);
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
-    hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas);
+    hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas, tbuf ? 1 : 0);
+    if (tbuf) hipLaunchKernelGGL(k_march_train_fill, dim3(N), dim3(RM_RAY_BLOCK), 0, s, a, rays, bases, tbuf, xyzs, dirs, deltas);
     NGP_CHECK_LAUNCH("march_rays_train");
     return NGP_OK;
 }

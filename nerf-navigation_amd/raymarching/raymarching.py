@@ -141,7 +141,9 @@ class _march_rays_train(Function):
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
 
         L = _hip.lib()
-        ws = _hip.workspace(L.ngp_march_rays_train_workspace(N), dev)
+        # with room for every sample's t (N * max_steps floats, up to 256 MiB) the second pass does not march again
+        full = L.ngp_march_rays_train_workspace_full(N, max_steps)
+        ws = _hip.workspace(full if full <= (256 << 20) else L.ngp_march_rays_train_workspace(N), dev)
         _hip.check(L.ngp_march_rays_train(_hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), bound, dt_gamma,
                                           max_steps, N, C, H, M, _hip.ptr(nears.contiguous()), _hip.ptr(fars.contiguous()),
                                           _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays),
