@@ -364,6 +364,9 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_S
 #define RV_S 12                        // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
 #endif
+#ifndef RV_XCD_QUEUES
+#define RV_XCD_QUEUES 1        // 1: eight ray queues, one per XCD (image bands), with stealing; 0: one global queue
+#endif
 #ifndef RV_BLOCK_THREADS
 #define RV_BLOCK_THREADS 512
 #endif
@@ -405,6 +408,9 @@ struct rf_frame {
     float bg[3];
     float* image; float* depth; float* weights_sum;
     uint32_t* stats; uint32_t* queue;
+#ifdef RV_COUNTERS
+    uint32_t* hist;                                    // debug timeline (4 x 512 bins) in the tile-order area of the workspace
+#endif
     const uint32_t* coarse;          // [C * (H/4)^3 / 32] words, or null when H is not a power of two >= 4
     uint32_t coarse_words;           // words per cascade level
     uint32_t tile_w;                 // image width in pixels when the rays are a row-major image (8x8 tile order), else 0
@@ -1008,14 +1014,25 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     float t = 0, last_t = 0, near = 0, far = 0;
     float ws = 0, dacc = 0, cr = 0, cg = 0, cb = 0, tcomp = 0;
     bool exhausted = false;
+#if RV_XCD_QUEUES
+    uint32_t rv_q = blockIdx.x & 7u, rv_q_seen = 0;        // blockIdx % 8 labels the workgroups that share an XCD
+#endif
     rv_block_cache bc;                                 // bitfield word of the block the ray last tested (block ids are global: stays valid across rays)
-    uint32_t n_samples_local = 0, n_tiles = 0;
+    uint32_t n_samples_local = 0, n_tiles = 0, n_capped_local = 0, n_hit_local = 0;
 #ifdef RV_COUNTERS
     uint32_t n_rounds = 0, n_trips = 0, n_probe[3] = {0, 0, 0};
     unsigned long long c_refill = 0, c_march = 0, c_tiles = 0, c_comp = 0;
     const unsigned long long c_start = __builtin_readcyclecounter();
     unsigned long long c_last = c_start;
 #define RV_TICK(acc) { const unsigned long long c_now = __builtin_readcyclecounter(); acc += c_now - c_last; c_last = c_now; }
+    uint32_t* rv_hist = F.hist;
+    unsigned long long rv_t0 = 0;
+    if (rv_hist) {
+        unsigned long long* p0 = reinterpret_cast<unsigned long long*>(F.queue + 24);
+        const unsigned long long now = wall_clock64();
+        const unsigned long long old = atomicCAS(p0, 0ull, now);
+        rv_t0 = __shfl(old ? old : now, 0, 64);
+    }
 #else
 #define RV_TICK(acc)
 #endif
@@ -1026,11 +1043,28 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             if (need) {
                 const uint32_t cnt = (uint32_t)__popcll(need);
                 uint32_t base = 0;
+#if RV_XCD_QUEUES
+                // Queue q holds the rays of image band q (tiles [T q / 8, T (q + 1) / 8) of 64 rays): the workgroups of one XCD
+                // start on the same band, so that the table lines neighbouring rays share are fetched into ONE L2 and
+                // not into eight.  A wave that finds its queue empty moves on to the next one (stealing keeps the load
+                // balanced; the lanes left without a ray wait one round).
+                const uint32_t n_tiles64 = (F.N + 63u) >> 6;
+                const uint32_t q_lo = (uint32_t)(((unsigned long long)n_tiles64 * rv_q) >> 3) << 6;
+                uint32_t q_hi = (uint32_t)(((unsigned long long)n_tiles64 * (rv_q + 1u)) >> 3) << 6;
+                q_hi = q_hi < F.N ? q_hi : F.N;
+                if (lane == 0) base = atomicAdd(F.queue + 32 + rv_q, cnt);
+                base = __shfl(base, 0, 64) + q_lo;
+#else
                 if (lane == 0) base = atomicAdd(F.queue, cnt);
                 base = __shfl(base, 0, 64);
+#endif
                 if (!active) {
                     const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+#if RV_XCD_QUEUES
+                    if (idx < q_hi) {
+#else
                     if (idx < F.N) {
+#endif
                         ray = rv_ray_of(idx, F.tile_w, F.tile_order);
                         const float* o = F.rays_o + 3ull * ray;
                         const float* d = F.rays_d + 3ull * ray;
@@ -1047,10 +1081,20 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                         active = true;
                     }
                 }
+#if RV_XCD_QUEUES
+                if (base + cnt >= q_hi) {                  // this queue has run dry: move on, until all eight have been seen
+                    rv_q = (rv_q + 1u) & 7u;
+                    if (++rv_q_seen == 8u) exhausted = true;
+                }
+#else
                 if (base + cnt >= F.N) exhausted = true;
+#endif
             }
         }
-        if (__ballot(active) == 0ull) break;
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;                                  // the queue ran dry under this wave: draw from the next one
+        }
         RV_TICK(c_refill)
 
         // ---- march: up to RV_S samples per lane within one shared probe budget ----
@@ -1058,6 +1102,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         bool ended = false;
 #ifdef RV_COUNTERS
         n_rounds++;
+        const unsigned long long rv_live = __ballot(active);
 #endif
         if (active) {
             // The ray's constants live across the field evaluation, where every register is taken, so the allocator keeps them
@@ -1259,16 +1304,42 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             F.image[3ull * ray + 2] = cb + (1 - ws) * F.bg[2];
             F.depth[ray] = fmaxf(dacc - near, 0.0f) / (far - near);
             F.weights_sum[ray] = ws;
-            if (capped) atomicAdd(F.stats + 1, 1u);
-            if (nsamp > 0) atomicAdd(F.stats + 2, 1u);
+            n_capped_local += capped ? 1u : 0u;        // counted per lane, added to F.stats once when the wave retires
+            n_hit_local += nsamp > 0 ? 1u : 0u;
             active = false;
         }
         RV_TICK(c_comp)
+#ifdef RV_COUNTERS
+        if (rv_hist) {                                  // debug timeline: per 20 us bin, samples / wave-rounds / live lanes / field-phase cycles
+            const unsigned long long now = wall_clock64();
+            const uint32_t bin = now > rv_t0 ? (uint32_t)((now - rv_t0) / 2000ull) : 0u;
+            uint32_t rs = (uint32_t)cnt;
+            #pragma unroll
+            for (int off = 32; off > 0; off >>= 1) rs += __shfl_down(rs, off, 64);
+            if (lane == 0 && bin < 512u) {
+                atomicAdd(rv_hist + bin, rs); atomicAdd(rv_hist + 512 + bin, 1u);
+                atomicAdd(rv_hist + 1024 + bin, (uint32_t)__popcll(rv_live));
+            }
+        }
+#endif
     }
-    uint32_t tot = n_samples_local;
+#ifdef RV_COUNTERS
+    if (rv_hist && lane == 0) {
+        const unsigned long long now = wall_clock64();
+        const uint32_t bin = now > rv_t0 ? (uint32_t)((now - rv_t0) / 2000ull) : 0u;
+        if (bin < 512u) atomicAdd(rv_hist + 1536 + bin, 1u);
+    }
+#endif
+    uint32_t tot = n_samples_local, tot_capped = n_capped_local, tot_hit = n_hit_local;
     #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        tot += __shfl_down(tot, off, 64);
+        tot_capped += __shfl_down(tot_capped, off, 64);
+        tot_hit += __shfl_down(tot_hit, off, 64);
+    }
     if (lane == 0 && tot) atomicAdd(F.stats, tot);
+    if (lane == 0 && tot_capped) atomicAdd(F.stats + 1, tot_capped);
+    if (lane == 0 && tot_hit) atomicAdd(F.stats + 2, tot_hit);
     if (lane == 0 && n_tiles) atomicAdd(F.stats + 3, n_tiles);
 #ifdef RV_COUNTERS
     if (lane == 0) { atomicAdd(F.queue + 1, n_rounds); atomicAdd(F.queue + 2, n_trips); }
@@ -1320,7 +1391,7 @@ extern "C" int ngp_render_set_block_skip(int enabled) {
     return old;
 }
 
-static constexpr size_t RV_WS_COARSE = 128, RV_WS_TILES = 128 + 48 * 1024;
+static constexpr size_t RV_WS_COARSE = 256, RV_WS_TILES = 256 + 48 * 1024;   // header: global queue + debug words | 8 band queues
 extern "C" size_t ngp_render_frame_workspace(uint32_t N) {
     // ray queue | coarse occupancy map (<= 48 KiB) | per-tile estimates and tile order (one u32 each per 64 rays)
     return RV_WS_TILES + 2 * sizeof(uint32_t) * (size_t)ngp_div_up(N, 64u);
@@ -1334,7 +1405,7 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     rf_params P;
     int rc = rf_fill_params("render_frame", field_host, P);
     if (rc != NGP_OK) return rc;
-    NGP_REQUIRE(stats && workspace && workspace_bytes >= 128, "render_frame: stats / workspace missing");
+    NGP_REQUIRE(stats && workspace && workspace_bytes >= RV_WS_COARSE, "render_frame: stats / workspace missing");
     NGP_REQUIRE(aabb_host && bg_color3_host, "render_frame: aabb / bg_color are host pointers and must not be null");
     NGP_REQUIRE(C >= 1 && C <= 16 && Hgrid >= 1 && Hgrid <= 1024 && max_steps >= 1, "render_frame: bad C/H/max_steps");
     hipStream_t s = (hipStream_t)stream;
@@ -1350,6 +1421,15 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     for (int i = 0; i < 3; i++) F.bg[i] = bg_color3_host[i];
     F.image = image; F.depth = depth; F.weights_sum = weights_sum;
     F.stats = stats; F.queue = (uint32_t*)workspace;
+#ifdef RV_COUNTERS
+    F.hist = nullptr;
+#ifdef RV_TIMELINE                                      // the timeline's atomics perturb the cycle counters: a build of its own
+    if (workspace_bytes >= RV_WS_TILES + 2048 * sizeof(uint32_t)) {
+        F.hist = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + RV_WS_TILES);
+        if (hipMemsetAsync(F.hist, 0, 2048 * sizeof(uint32_t), s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "render_frame: memset failed");
+    }
+#endif
+#endif
     F.tile_w = 0;
     const uint32_t hint = image_width;
     if (hint >= 8 && hint % 8 == 0 && N % hint == 0 && (N / hint) % 8 == 0) F.tile_w = hint;

@@ -22,6 +22,8 @@ ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(d
 ren.load_density_grid(W.density_grid())
 o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(res, res), res, res)
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+for _ in range(3):                                      # warm-up launches: the counters below are those of a warm frame
+    ren.render_fused(o[None], d[None], bg_color=1, image_width=res)
 out = ren.render_fused(o[None], d[None], bg_color=1, image_width=res, return_workspace=True)
 torch.cuda.synchronize()
 st = out["stats"].cpu().numpy().astype(np.int64)
@@ -33,8 +35,20 @@ if ws[1]:
     print("lane probes: fine-tested", ws[3], "(of which samples", st[0], ") coarse-empty", ws[4], "super-empty", ws[5])
 
     c = out["workspace"][32:88].view(torch.int64).cpu().numpy().view(np.uint64)
-    nw = 4096.0
+    nw = 2048.0                                             # 256 workgroups x 8 waves
     cmin = float(np.uint64(0xFFFFFFFFFFFFFFFF) - c[6])
     print("wave cycles (mean per wave, M): refill %.2f march %.2f tiles %.2f composite %.2f total %.2f | max %.2f min %.2f" % (
         float(c[0]) / nw / 1e6, float(c[1]) / nw / 1e6, float(c[2]) / nw / 1e6, float(c[3]) / nw / 1e6, float(c[4]) / nw / 1e6,
         float(c[5]) / 1e6, cmin / 1e6))
+    # timeline (-DRV_COUNTERS -DRV_TIMELINE build; its atomics perturb the cycle counters above): 20 us bins of samples / wave-rounds / live lanes at round start / waves finishing
+    off = 256 + 48 * 1024
+    if out["workspace"].numel() >= off + 4 * 2048:
+        h = out["workspace"][off:off + 4 * 2048].view(torch.int32).cpu().numpy().astype(np.int64).reshape(4, 512)
+        last = int(np.nonzero(h[1])[0].max()) + 1 if h[1].any() else 0
+        step = 5
+        print("timeline, %d us bins: t_us  Gsamples/s  rounds  live-lanes/round  samples/round  waves-finished(cum)" % (20 * step))
+        fin = 0
+        for b in range(0, last, step):
+            smp, rnd, live, f = (int(h[k, b:b + step].sum()) for k in range(4))
+            fin += f
+            print("  %5d  %6.2f  %6d  %5.1f  %6.1f  %5d" % (20 * b, smp / (20e-6 * step) / 1e9, rnd, live / max(rnd, 1), smp / max(rnd, 1), fin))
