@@ -91,7 +91,9 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--cpu-res", type=int, default=144, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--path", default="fused", choices=["fused", "per_op", "per_op_fused_field"], help="per_op = the reference-shaped op-by-op loop")
+    ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "per_op", "per_op_fused_field"],
+                    help="fused = headline (rays resident); fused_camera = rays generated inside the frame kernel from the pose; "
+                         "fused_torch_rays = torch get_rays per frame + fused; per_op = the reference-shaped op-by-op loop")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render = the headline metric; train = secondary: training steps (configs 3 / 5), 4096 rays per step per GPU")
     args = ap.parse_args()
@@ -133,14 +135,23 @@ def main():
     n_poses = 8
     # every rank walks the same orbit, phase-shifted by its rank, so ranks never render the same view at the same step
     from ngp import sharding
-    rays = []
+    rays, poses = [], []
     for view in sharding.pose_indices(rank, world, n_poses):
-        o, d = W.get_rays(W.orbit_pose(view, n_poses * world), intr, H, Wd)
+        poses.append(W.orbit_pose(view, n_poses * world).astype(np.float32))
+        o, d = W.get_rays(poses[-1], intr, H, Wd)
         rays.append((torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]))
     N = H * Wd
+    fused = args.path.startswith("fused")
+    poses_dev = [torch.from_numpy(p)[None].to(dev) for p in poses]
 
     def frame(k):
         o, d = rays[k % n_poses]
+        if args.path == "fused_camera":                      # secondary: get_rays inside the kernel (ngp_render_frame_camera)
+            return ren.render_fused_camera(poses[k % n_poses], intr, H, Wd, dt_gamma=0, bg_color=1, max_steps=1024)
+        if args.path == "fused_torch_rays":                  # secondary: what a caller pays with the reference's torch get_rays
+            from ngp.nav import get_rays
+            r = get_rays(poses_dev[k % n_poses], intr, H, Wd)
+            return ren.render_fused(r["rays_o"], r["rays_d"], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
         if args.path == "fused":
             return ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
@@ -164,13 +175,13 @@ def main():
         ev[k][0].record()
         out = frame(k)
         ev[k][1].record()
-        if args.path == "fused":
+        if fused:
             stats.append(out["stats"])
     sync_all()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    if args.path == "fused":
+    if fused:
         samples = int(torch.stack(stats)[:, 0].to(torch.int64).sum().item())
         capped = int(torch.stack(stats)[:, 1].to(torch.int64).sum().item())
     else:
@@ -221,7 +232,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "k_render_frame_multi" if args.path == "fused" else "per-op loop (many kernels)",
+            "kernel": "k_render_frame_multi" if fused else "per-op loop (many kernels)",
             "avg_launch_ms": 1e3 * avg_kernel_s,
             "algorithmic_bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
             "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,

@@ -245,6 +245,22 @@ int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const f
                      float* image, float* depth, float* weights_sum, uint32_t* stats,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- camera rays (reference: get_rays, nerf/utils.py:53-116) ----
+ * pose: host, row-major 4x4 (or the first 3 rows of it) camera-to-world; intrinsics: host [4] = fx, fy, cx, cy.
+ * Ray k is that of pixel inds[k] (device int64, row-major pixel index, the `inds` of the reference's random branches) or
+ * of pixel k when inds is null (N == H*W, the full-image branch).  rays_o, rays_d [N,3] f32 device.
+ * Arithmetic and its order: csrc/ngp_camera.h (equal to the torch formula to ~1 ulp; bit-exact against the oracle). */
+int ngp_get_rays(const float* pose_host, const float* intrinsics_host, uint32_t H, uint32_t W,
+                 const int64_t* inds, uint32_t N, float* rays_o, float* rays_d, void* stream);
+/* ngp_render_frame with get_rays fused into the kernel: the H*W rays of the camera, never materialised.
+ * Bit-identical to ngp_get_rays(..., NULL, H*W, ...) followed by ngp_render_frame(..., N = H*W, image_width = W, ...).
+ * workspace: ngp_render_frame_workspace(H*W) bytes. */
+int ngp_render_frame_camera(const ngp_field_t* field_host, const float* pose_host, const float* intrinsics_host, uint32_t H, uint32_t W,
+                            const float* aabb, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                            float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                            float* image, float* depth, float* weights_sum, uint32_t* stats,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 #include "ngp_march.h"
+#include "ngp_camera.h"
 
 #ifndef RF_MIX_BLEND
 #define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
@@ -401,7 +402,8 @@ static constexpr uint32_t RV_LDS_SH = RV_WAVES * 64 * 32;              // 16 hal
 static constexpr uint32_t RV_LDS_LV = 4 * 96;                          // rf_lane_levels of the 4 lane groups
 
 struct rf_frame {
-    const float* rays_o; const float* rays_d; uint32_t N;
+    const float* rays_o; const float* rays_d; uint32_t N;   // rays_o == null: the rays are those of `cam` (pixel = ray id)
+    ngp_camera cam;
     float aabb[6]; float min_near;
     const uint8_t* bitfield; uint32_t C, H;
     float dt_gamma; uint32_t max_steps;
@@ -1066,8 +1068,14 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                     if (idx < F.N) {
 #endif
                         ray = rv_ray_of(idx, F.tile_w, F.tile_order);
-                        const float* o = F.rays_o + 3ull * ray;
-                        const float* d = F.rays_d + 3ull * ray;
+                        float o[3], d[3];
+                        if (F.rays_o) {
+                            #pragma unroll
+                            for (int k = 0; k < 3; k++) { o[k] = F.rays_o[3ull * ray + k]; d[k] = F.rays_d[3ull * ray + k]; }
+                        } else {                           // camera mode: get_rays fused into the refill (nerf/utils.py:98-108)
+                            o[0] = F.cam.t[0]; o[1] = F.cam.t[1]; o[2] = F.cam.t[2];
+                            ngp_camera_ray(F.cam, ray, d);
+                        }
                         ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
                         m.ox = o[0]; m.oy = o[1]; m.oz = o[2];
                         m.dx = d[0]; m.dy = d[1]; m.dz = d[2];
@@ -1397,11 +1405,25 @@ extern "C" size_t ngp_render_frame_workspace(uint32_t N) {
     return RV_WS_TILES + 2 * sizeof(uint32_t) * (size_t)ngp_div_up(N, 64u);
 }
 
-extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
-                                uint32_t image_width, const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
-                                float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
-                                float* image, float* depth, float* weights_sum, uint32_t* stats,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+static int rv_fill_camera(const char* who, const float* pose_host, const float* intrinsics_host, uint32_t H, uint32_t W, ngp_camera& cam) {
+    NGP_REQUIRE(pose_host && intrinsics_host, "camera: pose / intrinsics are host pointers and must not be null");
+    NGP_REQUIRE(H >= 1 && W >= 1 && (uint64_t)H * W <= 0xFFFFFFFFull, "camera: bad image size");
+    NGP_REQUIRE(intrinsics_host[0] != 0.0f && intrinsics_host[1] != 0.0f, "camera: zero focal length");
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) cam.r[3 * r + c] = pose_host[4 * r + c];
+        cam.t[r] = pose_host[4 * r + 3];
+    }
+    cam.fx = intrinsics_host[0]; cam.fy = intrinsics_host[1]; cam.cx = intrinsics_host[2]; cam.cy = intrinsics_host[3];
+    cam.W = W; cam.H = H;
+    (void)who;
+    return NGP_OK;
+}
+
+static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, const ngp_camera* cam, uint32_t N,
+                           uint32_t image_width, const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                           float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                           float* image, float* depth, float* weights_sum, uint32_t* stats,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     rf_params P;
     int rc = rf_fill_params("render_frame", field_host, P);
     if (rc != NGP_OK) return rc;
@@ -1412,9 +1434,10 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     if (hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(workspace, 0, RV_WS_COARSE, s) != hipSuccess)
         return ngp_fail(NGP_ELAUNCH, "render_frame: memset failed");
     if (N == 0) return NGP_OK;
-    NGP_REQUIRE(rays_o && rays_d && bitfield && image && depth && weights_sum, "render_frame: null pointer");
+    NGP_REQUIRE((cam || (rays_o && rays_d)) && bitfield && image && depth && weights_sum, "render_frame: null pointer");
     rf_frame F;
-    F.rays_o = rays_o; F.rays_d = rays_d; F.N = N;
+    F.rays_o = cam ? nullptr : rays_o; F.rays_d = cam ? nullptr : rays_d; F.N = N;
+    F.cam = cam ? *cam : ngp_camera{};
     for (int i = 0; i < 6; i++) F.aabb[i] = aabb_host[i];
     F.min_near = min_near; F.bitfield = bitfield; F.C = C; F.H = Hgrid;
     F.dt_gamma = dt_gamma; F.max_steps = max_steps;
@@ -1490,5 +1513,59 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
     hipLaunchKernelGGL(k_render_frame, dim3(blocks), dim3(RV_BLOCK), lds, s, P, F);
 #endif
     NGP_CHECK_LAUNCH("render_frame");
+    return NGP_OK;
+}
+
+extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
+                                uint32_t image_width, const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                                float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                                float* image, float* depth, float* weights_sum, uint32_t* stats,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    return rv_render_frame(field_host, rays_o, rays_d, nullptr, N, image_width, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
+                           bg_color3_host, image, depth, weights_sum, stats, workspace, workspace_bytes, stream);
+}
+
+// The same frame from a camera instead of ray arrays: get_rays (nerf/utils.py:53-116, full-image branch) runs inside the
+// kernel's refill, one ray per pixel in row-major order (ngp_camera.h); bit-identical to ngp_get_rays + ngp_render_frame.
+extern "C" int ngp_render_frame_camera(const ngp_field_t* field_host, const float* pose_host, const float* intrinsics_host, uint32_t H, uint32_t W,
+                                       const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                                       float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                                       float* image, float* depth, float* weights_sum, uint32_t* stats,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    ngp_camera cam;
+    const int rc = rv_fill_camera("render_frame_camera", pose_host, intrinsics_host, H, W, cam);
+    if (rc != NGP_OK) return rc;
+    return rv_render_frame(field_host, nullptr, nullptr, &cam, H * W, W, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
+                           bg_color3_host, image, depth, weights_sum, stats, workspace, workspace_bytes, stream);
+}
+
+// get_rays as an op of its own (nerf/utils.py:53-116): ray k belongs to pixel inds[k] (row-major, inds on the device) or to
+// pixel k when inds is null (then N must be H * W).  rays_o, rays_d: [N, 3].
+__global__ __launch_bounds__(256) void k_get_rays(ngp_camera cam, const int64_t* __restrict__ inds, uint32_t N,
+                                                  float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    uint32_t pixel = k;
+    if (inds) {
+        const int64_t p = inds[k];
+        const int64_t last = (int64_t)cam.W * cam.H - 1;
+        pixel = (uint32_t)(p < 0 ? 0 : p > last ? last : p);      // torch.gather would raise; out-of-range indices are clamped
+    }
+    float d[3];
+    ngp_camera_ray(cam, pixel, d);
+    #pragma unroll
+    for (int c = 0; c < 3; c++) { rays_o[3ull * k + c] = cam.t[c]; rays_d[3ull * k + c] = d[c]; }
+}
+
+extern "C" int ngp_get_rays(const float* pose_host, const float* intrinsics_host, uint32_t H, uint32_t W,
+                            const int64_t* inds, uint32_t N, float* rays_o, float* rays_d, void* stream) {
+    ngp_camera cam;
+    const int rc = rv_fill_camera("get_rays", pose_host, intrinsics_host, H, W, cam);
+    if (rc != NGP_OK) return rc;
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(inds || (uint64_t)N == (uint64_t)H * W, "get_rays: N must be H * W when inds is null");
+    NGP_REQUIRE(rays_o && rays_d, "get_rays: null pointer");
+    hipLaunchKernelGGL(k_get_rays, dim3(ngp_div_up(N, 256u)), dim3(256), 0, (hipStream_t)stream, cam, inds, N, rays_o, rays_d);
+    NGP_CHECK_LAUNCH("get_rays");
     return NGP_OK;
 }

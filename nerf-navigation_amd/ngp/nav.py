@@ -54,6 +54,25 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, generator=None):
     return results
 
 
+def get_rays_native(pose, intrinsics, H, W, inds=None, device=None):
+    """get_rays for ONE camera as a native op (ngp_get_rays, csrc/ngp_camera.h): pose [4,4] cam2world, full image when
+    `inds` is None, else the pixels `inds` [N] (int64, row-major).  Returns rays_o, rays_d [N,3] float32 on `device`.
+    Equal to `get_rays` to ~1 ulp (torch may associate the norm and the 3x3 product differently)."""
+    import ngp_hip as _hip                                   # the C-ABI library: fails loudly when it is not built
+    if device is None:
+        device = inds.device if inds is not None else (pose.device if isinstance(pose, torch.Tensor) and pose.is_cuda else torch.device("cuda"))
+    N = int(H) * int(W) if inds is None else int(inds.numel())
+    rays_o = torch.empty(N, 3, dtype=torch.float32, device=device)
+    rays_d = torch.empty(N, 3, dtype=torch.float32, device=device)
+    if inds is not None:
+        inds = inds.to(device=device, dtype=torch.int64).contiguous()
+    pose_h, intr_h = _hip.camera_args(pose, intrinsics)
+    with torch.cuda.device(device):
+        _hip.check(_hip.lib().ngp_get_rays(pose_h, intr_h, int(H), int(W), _hip.ptr(inds) if inds is not None else None, N,
+                                           _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.stream()), "get_rays")
+    return rays_o, rays_d
+
+
 class NavQueries:
     """density_fn / render_fn / get_rays_fn for Planner and Estimator, bound to a frozen renderer."""
 

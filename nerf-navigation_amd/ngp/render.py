@@ -161,6 +161,31 @@ class NGPRenderer(nn.Module):
             out["workspace"] = ws                          # debug builds (-DRV_COUNTERS) leave counters behind the ray queue
         return out
 
+    @torch.no_grad()
+    def render_fused_camera(self, pose, intrinsics, H, W, dt_gamma=0, bg_color=None, max_steps=1024):
+        """render_fused for the H x W rays of one camera (pose [4,4] or [3,4] cam2world, intrinsics fx, fy, cx, cy) without
+        materialising them: get_rays (nerf/utils.py:53-116) runs inside the frame kernel.  Same results, bit for bit, as
+        `render_fused(*get_rays_native(...), image_width=W)`."""
+        device = self.density_bitfield.device
+        N = int(H) * int(W)
+        image = torch.empty(N, 3, dtype=torch.float32, device=device)
+        depth = torch.empty(N, dtype=torch.float32, device=device)
+        weights_sum = torch.empty(N, dtype=torch.float32, device=device)
+        stats = torch.empty(4, dtype=torch.int32, device=device)
+        if bg_color is None:
+            bg_color = 1
+        bg = (ctypes.c_float * 3)(*([float(bg_color)] * 3 if np.isscalar(bg_color) else [float(v) for v in bg_color]))
+        aabb = (ctypes.c_float * 6)(*[float(v) for v in self._aabb().tolist()])
+        pose_h, intr_h = _hip.camera_args(pose, intrinsics)
+        L = _hip.lib()
+        ws = _hip.workspace(L.ngp_render_frame_workspace(N), device)
+        f = self.field.fused_state()
+        _hip.check(L.ngp_render_frame_camera(ctypes.byref(f), pose_h, intr_h, int(H), int(W), aabb, self.min_near,
+                                             _hip.ptr(self.density_bitfield), self.cascade, self.grid_size, dt_gamma, max_steps, bg,
+                                             _hip.ptr(image), _hip.ptr(depth), _hip.ptr(weights_sum), _hip.ptr(stats),
+                                             _hip.ptr(ws), ws.numel(), _hip.stream()), "render_frame_camera")
+        return {"image": image.view(H, W, 3), "depth": depth.view(H, W), "weights_sum": weights_sum, "stats": stats}
+
     # ------------------------------------------------------------------------------------------------------------
     # fixed-step path (nav loop)
     # ------------------------------------------------------------------------------------------------------------

@@ -59,6 +59,9 @@ _SIGNATURES = {
     "ngp_render_set_block_skip": (c_int, [c_int]),
     "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_get_rays": (c_int, [c_vp, c_vp, c_u32, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_render_frame_camera": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
+                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -141,3 +144,15 @@ def dtype_code(dt):
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def camera_args(pose, intrinsics):
+    """host arguments of ngp_get_rays / ngp_render_frame_camera: pose [4,4] or [3,4] (tensor, array or nested list) as 16
+    row-major floats (last row ignored by the library), intrinsics (fx, fy, cx, cy) as 4 floats"""
+    if isinstance(pose, torch.Tensor):
+        pose = pose.detach().cpu().tolist()
+    rows = [[float(v) for v in r] for r in pose]
+    if len(rows) not in (3, 4) or any(len(r) != 4 for r in rows):
+        raise ValueError("pose must be [4,4] or [3,4]")
+    flat = [v for r in rows[:3] for v in r] + [0.0, 0.0, 0.0, 1.0]
+    return (ctypes.c_float * 16)(*flat), (ctypes.c_float * 4)(*[float(v) for v in intrinsics])

@@ -130,3 +130,22 @@ def render_single_march(field_fn, rays_o, rays_d, bitfield, bound, cascade, H=12
 
 def psnr(pred, truth):
     return float(-10 * np.log10(np.mean((np.asarray(pred, np.float64) - np.asarray(truth, np.float64)) ** 2)))
+
+
+def camera_rays(pose, intrinsics, H, W, inds=None):
+    """get_rays (nerf/utils.py:53-116, arithmetic of :98-108) for one camera in binary32 with the operation order the
+    kernels use (csrc/ngp_camera.h): every numpy float32 operation rounds once, like the device code built with
+    -ffp-contract=off.  pose [4,4] cam2world; full image (row-major) or the pixels `inds`.  -> rays_o, rays_d [N,3]."""
+    f = np.float32
+    pose = np.asarray(pose, dtype=f)
+    fx, fy, cx, cy = (f(v) for v in intrinsics)
+    pix = np.arange(H * W, dtype=np.int64) if inds is None else np.clip(np.asarray(inds, dtype=np.int64), 0, H * W - 1)
+    row, col = pix // W, pix % W
+    xs = ((col.astype(f) + f(0.5)) - cx) / fx
+    ys = ((row.astype(f) + f(0.5)) - cy) / fy
+    n = np.sqrt((xs * xs + ys * ys) + f(1.0))
+    ux, uy, uz = xs / n, ys / n, f(1.0) / n
+    R = pose[:3, :3]
+    rays_d = np.stack([(ux * R[k, 0] + uy * R[k, 1]) + uz * R[k, 2] for k in range(3)], axis=-1).astype(f)
+    rays_o = np.broadcast_to(pose[:3, 3], rays_d.shape).astype(f).copy()
+    return rays_o, rays_d

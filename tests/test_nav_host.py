@@ -32,3 +32,26 @@ def test_get_rays_full_image_and_sampling_branches_cpu():
     assert bool((em["inds_coarse"] == 128 * 100 + 7).all())
     rows, cols = em["inds"] // Wd, em["inds"] % Wd
     assert bool((rows == int(100 * H / 128)).all()) and bool(((cols >= int(7 * Wd / 128)) & (cols <= int(8 * Wd / 128))).all())
+
+
+def test_oracle_camera_rays_match_the_torch_formula():
+    """oracle/render_oracle.py: camera_rays (the binary32 operation order of csrc/ngp_camera.h) against ngp.nav.get_rays
+    (the reference's torch formula, nerf/utils.py:98-108) on the CPU: equal to rounding, unit length, rays_o = translation."""
+    import numpy as np
+    import torch
+    from oracle import render_oracle as R
+    from ngp.nav import get_rays
+    rng = np.random.default_rng(4)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = q
+    pose[:3, 3] = (0.3, -1.2, 2.0)
+    intr = (95.0, 97.5, 50.3, 29.1)
+    H, W = 60, 101
+    o, d = R.camera_rays(pose, intr, H, W)
+    t = get_rays(torch.from_numpy(pose)[None], intr, H, W)
+    assert d.dtype == np.float32 and np.array_equal(o, t["rays_o"][0].numpy())
+    assert np.max(np.abs(d - t["rays_d"][0].numpy())) < 1e-6 and np.max(np.abs(np.linalg.norm(d, axis=-1) - 1)) < 1e-6
+    inds = rng.integers(0, H * W, size=300)
+    o2, d2 = R.camera_rays(pose, intr, H, W, inds=inds)
+    assert np.array_equal(d2, d[inds]) and o2.shape == (300, 3)
