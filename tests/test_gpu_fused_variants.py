@@ -148,3 +148,18 @@ def test_other_grid_sizes(oracle, dev, grid_h):
     assert abs(int(stats[0]) - ref["samples"]) <= max(8, 2e-3 * ref["samples"]) and stats[0] > 500
     assert stats[2] == int((ref["consumed"] > 0).sum())
     assert np.max(np.abs(out["image"][0].cpu().numpy() - ref["image"])) < 8e-3
+
+
+@pytest.mark.parametrize("n_rays", [1, 7, 70, 513])
+def test_tiny_frames_leave_most_band_queues_empty(oracle, dev, n_rays):
+    """fewer 64-ray tiles than ray queues (one per XCD band): empty bands are stepped over, every ray is rendered once"""
+    W, model, bf, ren = build(dev, 2.0)
+    o, d = W.get_rays(W.orbit_pose(2), W.intrinsics(48, 48), 48, 48)
+    pick = np.random.default_rng(n_rays).permutation(o.shape[0])[:n_rays]
+    o, d = o[pick], d[pick]
+    ref = R.render_single_march(lambda x, dd: R.field_forward(model, x, dd, 1.0), o, d, bf, 2.0, 2)
+    out = ren.render_fused(t(o, dev)[None], t(d, dev)[None], bg_color=1)
+    stats = out["stats"].cpu().numpy()
+    assert abs(int(stats[0]) - ref["samples"]) <= 8 and stats[2] == int((ref["consumed"] > 0).sum())
+    assert np.max(np.abs(out["image"].reshape(-1, 3).cpu().numpy() - ref["image"])) < 5e-3
+    assert np.isfinite(out["weights_sum"].cpu().numpy()).all()
