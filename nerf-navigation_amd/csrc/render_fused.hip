@@ -23,6 +23,7 @@
 // Semantics vs the reference loop (DESIGN.md "Fused path"): each ray is marched by a single resumable march from
 // `near` (the reference re-enters march_rays every n_step samples); a ray consumes at most max_steps samples (the
 // reference offers between max_steps and max_steps+7 depending on the schedule; such rays are counted in stats[1]).
+#include <atomic>
 #include "ngp_mlp.h"
 #include "ngp_sh.h"
 #include "ngp_march.h"
@@ -1497,11 +1498,15 @@ static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, c
         F.tile_order = order;
     }
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the raised dynamic-LDS limit is a per-device function attribute: set it once on every device this process renders on
+    static std::atomic<unsigned long long> attr_devices{0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0) return ngp_fail(NGP_ELAUNCH, "render_frame: no current device");
+    const unsigned long long device_bit = 1ull << (device & 63);
+    if (device >= 64 || !(attr_devices.load(std::memory_order_acquire) & device_bit)) {
         if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return ngp_fail(NGP_ELAUNCH, "render_frame: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_devices.fetch_or(device_bit, std::memory_order_release);
     }
     // persistent grid: RV_BLOCKS_PER_CU workgroups per CU, fewer when the frame is small
     uint32_t blocks = 256 * RV_BLOCKS_PER_CU;
