@@ -139,6 +139,13 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                              int align_corners, int dtype, void* stream);
+/* The input gradient of grid_encode_backward WITHOUT the dy_dx tensor: recomputes the Jacobian from the table
+ * (gridencoder.cu:180-223 arithmetic) and contracts it with grad in kernel_input_backward's order (gridencoder.cu:317-343):
+ * bit-identical to forward(calc_grad_inputs=1) + backward(calc_grad_inputs=1), without writing and re-reading
+ * B*L*D*C values.  grad [L,B,C] and grad_inputs [B,D] have the table's dtype; D in {2,3}, C in {1,2,4,8}. */
+int ngp_grid_encode_backward_inputs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                    void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* _shencoder  (reference: shencoder/src/shencoder.h:10,13)                  */

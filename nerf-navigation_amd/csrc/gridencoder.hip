@@ -28,13 +28,15 @@ static void ge_fill_levels(ge_levels& lv, uint32_t L, float S, uint32_t H) {
 template <typename T> struct ge_num;
 template <> struct ge_num<float> {
     static __device__ __forceinline__ float rnd(float v) { return v; }
+    static __device__ __forceinline__ float mul_rnd(float a, float b) { return a * b; }
     static __device__ __forceinline__ float load(const float* p) { return *p; }
     static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
 };
 template <> struct ge_num<_Float16> {
-    static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+    static __device__ __forceinline__ float rnd(float v) { return (float)ngp_f2h(v); }   // two roundings, see ngp_f2h
+    static __device__ __forceinline__ float mul_rnd(float a, float b) { return (float)ngp_f2h(a * b); }
     static __device__ __forceinline__ float load(const _Float16* p) { return (float)*p; }
-    static __device__ __forceinline__ void store(_Float16* p, float v) { *p = (_Float16)v; }
+    static __device__ __forceinline__ void store(_Float16* p, float v) { *p = ngp_f2h(v); }
 };
 
 template <typename T, uint32_t C> struct alignas(sizeof(T) * C) ge_vec { T v[C]; };
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
             static_assert(N_C == 2, "half scatter needs feature pairs");
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             h2 hv;
-            hv.x = (_Float16)v[0];                     // (__half)(w * grad) : gridencoder.cu:302
-            hv.y = (_Float16)v[1];
+            hv.x = ngp_f2h(v[0]);                      // (__half)(w * grad) : gridencoder.cu:302
+            hv.y = ngp_f2h(v[1]);
             pair_row[idx & 1u] = (uint32_t)row;
             pair_val[idx & 1u] = __builtin_bit_cast(uint32_t, hv);
             pair_act[idx & 1u] = send ? 1 : 0;
@@ -299,8 +301,8 @@ __global__ __launch_bounds__(256) void k_grid_backward(const T* __restrict__ gra
             static_assert(sizeof(T) != 2 || N_C == 2, "half scatter needs feature pairs");
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             h2 hv;
-            hv.x = (_Float16)v[0];                     // (__half)(w * grad) : gridencoder.cu:302
-            hv.y = (_Float16)v[1];
+            hv.x = ngp_f2h(v[0]);                      // (__half)(w * grad) : gridencoder.cu:302
+            hv.y = ngp_f2h(v[1]);
             __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gg + row), hv);
         } else {
             #pragma unroll
@@ -327,6 +329,86 @@ __global__ __launch_bounds__(256) void k_grid_input_backward(const T* __restrict
         }
     }
     grad_inputs[t] = (T)result;
+}
+
+// The same input gradient without the [B, L*D*C] Jacobian in memory: one lane per point walks the levels, gathers the
+// 2^D corners once per level, forms dy_dx for the D directions exactly as k_grid_forward does (gridencoder.cu:180-223)
+// and adds grad * dy_dx in k_grid_input_backward's order (l outer, channel inner, rounded to T at every step), so the
+// result is bit-identical to the two-kernel route.  Saves writing and re-reading 96 values per point and the 24
+// second-time corner gathers of the forward's dy_dx branch.
+template <typename T, uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void k_grid_input_backward_recompute(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                       const T* __restrict__ grid, const int* __restrict__ offsets,
+                                                                       T* __restrict__ grad_inputs, uint32_t B, uint32_t L, ge_levels lv,
+                                                                       uint32_t gridtype, bool align_corners) {
+    using num = ge_num<T>;
+    using vec = ge_vec<T, C>;
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* in = inputs + (uint64_t)b * D;
+    float xin[D];
+    bool oob = false;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) { xin[d] = in[d]; oob |= (xin[d] < 0 || xin[d] > 1); }
+    float result[D];
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) result[d] = 0.0f;
+    if (!oob) {                                       // out of range: dy_dx is zero (gridencoder.cu:99-123)
+        for (uint32_t level = 0; level < L; level++) {
+            const vec* tab = reinterpret_cast<const vec*>(grid) + (uint32_t)offsets[level];
+            const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+            const float scale = lv.scale[level];
+            const uint32_t resolution = lv.resolution[level];
+            float pos[D];
+            uint32_t pg[D];
+            #pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = xin[d] * scale + (align_corners ? 0.0f : 0.5f);
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+            }
+            vec corner[1u << D];
+            #pragma unroll
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                uint32_t pl[D];
+                #pragma unroll
+                for (uint32_t d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
+                corner[idx] = tab[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+            }
+            vec g = reinterpret_cast<const vec*>(grad)[(uint64_t)level * B + b];
+            #pragma unroll
+            for (uint32_t gd = 0; gd < D; gd++) {
+                float rg[C];
+                #pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0.0f;
+                #pragma unroll
+                for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                    float wi = scale;
+                    uint32_t cl = 0;                  // corner number of the "left" neighbour: bit d set = upper cell in d
+                    #pragma unroll
+                    for (uint32_t nd = 0; nd < D - 1; nd++) {
+                        const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                        if ((idx & (1u << nd)) == 0) { wi *= 1 - pos[d]; }
+                        else { wi *= pos[d]; cl |= 1u << d; }
+                    }
+                    const vec left = corner[cl], right = corner[cl | (1u << gd)];
+                    #pragma unroll
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float diff = num::rnd((float)right.v[ch] - (float)left.v[ch]);
+                        const float prod = num::mul_rnd(wi, diff);
+                        rg[ch] = num::rnd(rg[ch] + prod);
+                    }
+                }
+                #pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float prod = num::rnd((float)g.v[ch] * rg[ch]);
+                    result[gd] = num::rnd(result[gd] + prod);
+                }
+            }
+        }
+    }
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) grad_inputs[(uint64_t)b * D + d] = (T)result[d];
 }
 
 // ---------------------------------------------------------------------------
@@ -443,5 +525,51 @@ extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, c
         : ge_backward_d<_Float16>(D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, calc_grad_inputs != 0, dy_dx, grad_inputs, gridtype, align_corners != 0, (hipStream_t)stream);
     if (rc != NGP_OK) return rc;
     NGP_CHECK_LAUNCH("grid_encode_backward");
+    return NGP_OK;
+}
+
+// grad_inputs [B,D] (dtype) from grad [L,B,C] without dy_dx: see k_grid_input_backward_recompute.
+template <typename T, uint32_t D>
+static int ge_backward_inputs_c(uint32_t C, const void* grad, const float* inputs, const void* emb, const int* offsets, void* gi,
+                                uint32_t B, uint32_t L, const ge_levels& lv, uint32_t gridtype, bool ac, hipStream_t s) {
+#define GE_LAUNCH_BI(CC) hipLaunchKernelGGL((k_grid_input_backward_recompute<T, D, CC>), dim3(ngp_div_up(B, 256u)), dim3(256), 0, s, \
+                                            (const T*)grad, inputs, (const T*)emb, offsets, (T*)gi, B, L, lv, gridtype, ac); return NGP_OK;
+    switch (C) {
+        case 1: GE_LAUNCH_BI(1)
+        case 2: GE_LAUNCH_BI(2)
+        case 4: GE_LAUNCH_BI(4)
+        case 8: GE_LAUNCH_BI(8)
+    }
+#undef GE_LAUNCH_BI
+    return ngp_fail(NGP_EINVAL, "grid_encode_backward_inputs: C must be 1, 2, 4 or 8");
+}
+
+extern "C" int ngp_grid_encode_backward_inputs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                               void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, void* stream) {
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(grad && inputs && embeddings && offsets && grad_inputs, "grid_encode_backward_inputs: null pointer");
+    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_backward_inputs: L must be in 1..32");
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_backward_inputs: dtype must be f32 or f16");
+    ge_levels lv;
+    ge_fill_levels(lv, L, S, H);
+    hipStream_t s = (hipStream_t)stream;
+    const bool ac = align_corners != 0;
+    int rc = NGP_EINVAL;
+    if (dtype == NGP_F32) {
+        switch (D) {
+            case 2: rc = ge_backward_inputs_c<float, 2>(C, grad, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, s); break;
+            case 3: rc = ge_backward_inputs_c<float, 3>(C, grad, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, s); break;
+            default: return ngp_fail(NGP_EINVAL, "grid_encode_backward_inputs: D must be 2 or 3");
+        }
+    } else {
+        switch (D) {
+            case 2: rc = ge_backward_inputs_c<_Float16, 2>(C, grad, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, s); break;
+            case 3: rc = ge_backward_inputs_c<_Float16, 3>(C, grad, inputs, embeddings, offsets, grad_inputs, B, L, lv, gridtype, ac, s); break;
+            default: return ngp_fail(NGP_EINVAL, "grid_encode_backward_inputs: D must be 2 or 3");
+        }
+    }
+    if (rc != NGP_OK) return rc;
+    NGP_CHECK_LAUNCH("grid_encode_backward_inputs");
     return NGP_OK;
 }

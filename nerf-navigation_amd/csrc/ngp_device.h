@@ -40,6 +40,15 @@ static inline uint32_t ngp_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a
 // device: scalar helpers
 // ---------------------------------------------------------------------------
 
+// binary32 -> binary16 of a value that may be the result of a multiplication.  Left alone, the compiler merges
+// `(_Float16)(a * b)` into v_fma_mixlo/mixhi_f16, and that instruction rounds the exact product ONCE to binary16
+// (measured on gfx950: different halves in ~1e-6 of the products, tools/cmp_frames.py), while the reference arithmetic
+// (a binary32 product stored to at::Half) rounds twice.  Pinning the binary32 value in a register keeps the two roundings.
+__device__ __forceinline__ _Float16 ngp_f2h(float v) {
+    asm("" : "+v"(v));
+    return (_Float16)v;
+}
+
 __device__ __forceinline__ float ngp_clampf(float x, float lo, float hi) {
     return fminf(hi, fmaxf(lo, x));                 // reference clamp(): raymarching.cu:36-38
 }

@@ -30,7 +30,9 @@
 #include "ngp_camera.h"
 
 #ifndef RF_MIX_BLEND
-#define RF_MIX_BLEND 1                 // blend products with v_fma_mix{lo,hi}_f16 (1) or cvt / mul / cvt (0): same bits
+#define RF_MIX_BLEND 0                 // 1: blend products with v_fma_mix{lo,hi}_f16 -- NOT the reference arithmetic: the instruction rounds
+                                       // the exact product once to half (1,637 of 1.92 M image values of an 800x800 frame change, up to
+                                       // 7.5e-5; 3.97 vs 3.99 ms).  0: cvt / mul / cvt with the binary32 product kept (ngp_f2h).
 #endif
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
@@ -112,7 +114,7 @@ __device__ __forceinline__ rf_iter_class rf_classify(const rf_lane_levels& lv) {
     return c;
 }
 
-__device__ __forceinline__ float rf_h(float v) { return (float)(_Float16)v; }   // round to half, back to float
+__device__ __forceinline__ float rf_h(float v) { return (float)ngp_f2h(v); }   // round to half, back to float
 
 struct rf_row2 { uint32_t lo, hi; };                                          // two consecutive rows
 __device__ __forceinline__ uint32_t rf_row(const rf_params& P, uint32_t byte_off) {
@@ -223,9 +225,9 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
 
 // Blend of one level.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):
 //   w = (wx * wy) * wz in binary32;  results[ch] += w * grid[...]  ==  half(float(result) + float(half(w * float(v))))
-// RF_MIX_BLEND: v_fma_mixlo/mixhi_f16 compute half(fma32(w, float(v), +0)) in one instruction per feature -- the same
-// two roundings (binary32 product, then binary16) as the cvt / mul / cvt sequence; the +0 addend only turns a -0 product
-// into +0, which a sum that starts at +0 cannot tell apart.  The packed-half add is the correctly rounded binary16 sum.
+// The product is rounded to binary32 and then to binary16 (ngp_f2h); v_fma_mixlo/mixhi_f16 would do it in one instruction
+// per feature but round only once (RF_MIX_BLEND, kept as a timing-only build).  The packed-half add is the correctly
+// rounded binary16 sum.
 __device__ __forceinline__ void rf_blend_pair(const rf_pair& in, int h, ngp_h8& out) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -246,7 +248,7 @@ __device__ __forceinline__ void rf_blend_pair(const rf_pair& in, int h, ngp_h8& 
             acc = acc + __builtin_bit_cast(h2, prod);
 #else
             const h2 v = __builtin_bit_cast(h2, in.raw[j][c]);
-            const h2 prod = {(_Float16)(wc * (float)v.x), (_Float16)(wc * (float)v.y)};
+            const h2 prod = {ngp_f2h(wc * (float)v.x), ngp_f2h(wc * (float)v.y)};
             acc = acc + prod;
 #endif
         }
@@ -694,7 +696,7 @@ __device__ __forceinline__ void rf_points_loop(const rf_params& P, const rf_iter
                 if (g == 1) v = sh[4 + j];
                 if (g == 2) v = sh[8 + j];
                 if (g == 3) v = sh[12 + j];
-                shq[n][j] = (_Float16)v;               // cat(...) enters FFMLP through cast_inputs=half
+                shq[n][j] = ngp_f2h(v);               // cat(...) enters FFMLP through cast_inputs=half
             }
             x[n] = rf_encode<false>(P, lv, cls, px, py, pz);
         }
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame(rf
                         float sh[16];
                         sh_eval<4>(m.dx, m.dy, m.dz, P.shn, sh);      // the ray's direction encoding, once per ray
                         #pragma unroll
-                        for (int j = 0; j < 16; j++) my_sh[j] = (_Float16)sh[j];
+                        for (int j = 0; j < 16; j++) my_sh[j] = ngp_f2h(sh[j]);
                         active = true;
                     }
                 }
@@ -1086,7 +1088,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                         float sh[16];
                         sh_eval<4>(m.dx, m.dy, m.dz, P.shn, sh);
                         #pragma unroll
-                        for (int j = 0; j < 16; j++) my_sh[j] = (_Float16)sh[j];
+                        for (int j = 0; j < 16; j++) my_sh[j] = ngp_f2h(sh[j]);
                         active = true;
                     }
                 }

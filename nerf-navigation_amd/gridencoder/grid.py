@@ -17,6 +17,13 @@ import ngp_hip as _hip
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 
+# True: the gradient w.r.t. the inputs is computed in backward from the table itself (ngp_grid_encode_backward_inputs) instead
+# of from a saved dy_dx [B, L*D*C] (grid.py:45-48): same bits, no 96-values-per-point tensor.  False: the reference's route.
+RECOMPUTE_INPUT_GRAD = True
+# ... from this many points on: the recomputing kernel walks the levels of a point in one lane (that keeps the reference's
+# summation order), so a small batch (the planner's 10,000 body points) does not fill the chip and is faster with dy_dx
+RECOMPUTE_MIN_POINTS = 32768
+
 
 class _grid_encode(Function):
     """reference: gridencoder/grid.py:19-87"""
@@ -40,13 +47,14 @@ class _grid_encode(Function):
             raise RuntimeError("inputs must be a float32 tensor")
 
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
-        if calc_grad_inputs:
+        recompute = bool(calc_grad_inputs) and RECOMPUTE_INPUT_GRAD and B >= RECOMPUTE_MIN_POINTS and D in (2, 3) and C in (1, 2, 4, 8)
+        if calc_grad_inputs and not recompute:
             dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype)
         else:
             dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)
 
         _hip.check(_hip.lib().ngp_grid_encode_forward(_hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets), _hip.ptr(outputs),
-                                                      B, D, C, L, float(S), H, int(calc_grad_inputs), _hip.ptr(dy_dx),
+                                                      B, D, C, L, float(S), H, int(calc_grad_inputs and not recompute), _hip.ptr(dy_dx),
                                                       gridtype, int(align_corners), _hip.dtype_code(embeddings.dtype),
                                                       _hip.stream()), "grid_encode_forward")
 
@@ -55,6 +63,7 @@ class _grid_encode(Function):
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype]
         ctx.calc_grad_inputs = calc_grad_inputs
+        ctx.recompute = recompute
         ctx.align_corners = align_corners
         return outputs
 
@@ -73,15 +82,21 @@ class _grid_encode(Function):
             return None, None, None, None, None, None, None, None
         grad_embeddings = torch.zeros_like(embeddings) if need_table else None
         if calc_grad_inputs:
-            grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
+            grad_inputs = (torch.empty_like if ctx.recompute else torch.zeros_like)(inputs, dtype=embeddings.dtype)
         else:
             grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
 
-        _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
-                                                       _hip.ptr(grad_embeddings) if need_table else None, B, D, C, L, float(S), H,
-                                                       int(calc_grad_inputs),
-                                                       _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
-                                                       _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")
+        if need_table or not ctx.recompute:
+            _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
+                                                           _hip.ptr(grad_embeddings) if need_table else None, B, D, C, L, float(S), H,
+                                                           int(calc_grad_inputs and not ctx.recompute),
+                                                           _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
+                                                           _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")
+        if ctx.recompute:
+            _hip.check(_hip.lib().ngp_grid_encode_backward_inputs(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
+                                                                  B, D, C, L, float(S), H, _hip.ptr(grad_inputs), gridtype,
+                                                                  int(ctx.align_corners), _hip.dtype_code(embeddings.dtype),
+                                                                  _hip.stream()), "grid_encode_backward_inputs")
 
         if calc_grad_inputs:
             return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None

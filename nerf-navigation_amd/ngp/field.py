@@ -92,16 +92,19 @@ class NGPFieldFF(nn.Module):
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         if mask is not None:
+            # network.py:139-146 gathers with `t[mask]` and scatters with `rgbs[mask] = h`; the row indices of a boolean mask
+            # are unique, so index_select / index_copy give the same values and the same gradients without autograd's
+            # sorting index_put(accumulate=True) backward (0.7 ms of a 4 ms pose-filter iteration)
             rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
-            if not mask.any():
+            rows = mask.nonzero(as_tuple=True)[0]
+            if rows.numel() == 0:
                 return rgbs
-            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+            d, geo_feat = d.index_select(0, rows), geo_feat.index_select(0, rows)
         d = self.encoder_dir(d)
         p = torch.zeros_like(geo_feat[..., :1])
         h = torch.sigmoid(self.color_net(torch.cat([d, geo_feat, p], dim=-1)))
         if mask is not None:
-            rgbs[mask] = h.to(rgbs.dtype)
-            return rgbs
+            return rgbs.index_copy(0, rows, h.to(rgbs.dtype))
         return h
 
     def get_params(self, lr):
@@ -183,14 +186,17 @@ class NGPField(nn.Module):
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         if mask is not None:
+            # network.py:139-146 gathers with `t[mask]` and scatters with `rgbs[mask] = h`; the row indices of a boolean mask
+            # are unique, so index_select / index_copy give the same values and the same gradients without autograd's
+            # sorting index_put(accumulate=True) backward (0.7 ms of a 4 ms pose-filter iteration)
             rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
-            if not mask.any():
+            rows = mask.nonzero(as_tuple=True)[0]
+            if rows.numel() == 0:
                 return rgbs
-            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+            d, geo_feat = d.index_select(0, rows), geo_feat.index_select(0, rows)
         h = torch.sigmoid(self._mlp(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1)))
         if mask is not None:
-            rgbs[mask] = h.to(rgbs.dtype)
-            return rgbs
+            return rgbs.index_copy(0, rows, h.to(rgbs.dtype))
         return h
 
     def get_params(self, lr):

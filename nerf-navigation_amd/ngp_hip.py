@@ -59,6 +59,7 @@ _SIGNATURES = {
     "ngp_render_set_block_skip": (c_int, [c_int]),
     "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_grid_encode_backward_inputs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_vp, c_u32, c_int, c_int, c_vp]),
     "ngp_get_rays": (c_int, [c_vp, c_vp, c_u32, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_render_frame_camera": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -202,3 +202,43 @@ def test_get_encoder_frequency(dev):
     from ngp.field import get_encoder
     enc, dim = get_encoder("frequency", input_dim=3, multires=6)
     assert dim == 39 and enc(torch.zeros(5, 3, device=dev)).shape == (5, 39)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("level_dim,gridtype,align", [(2, "hash", False), (4, "tiled", True), (1, "hash", False)])
+def test_grid_input_gradient_without_dy_dx_is_bit_identical(dev, half, level_dim, gridtype, align):
+    """gridencoder/grid.py:45-48,80-84 saves dy_dx [B, L*D*C] for the input gradient; the default route here recomputes it
+    in backward (ngp_grid_encode_backward_inputs).  Same bits as the saved-Jacobian route, with and without the table
+    gradient, including points outside [0,1] (zero gradient)."""
+    import gridencoder.grid as G
+    torch.manual_seed(3)
+    enc = G.GridEncoder(input_dim=3, num_levels=8, level_dim=level_dim, base_resolution=8, log2_hashmap_size=12,
+                        desired_resolution=256, gridtype=gridtype, align_corners=align).to(dev)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = torch.rand(5000, 3, device=dev) * 2.4 - 1.2                     # bound 1: about a third of the points are outside
+    gout = torch.randn(5000, 8 * level_dim, device=dev)
+
+    def run(recompute, frozen):
+        G.RECOMPUTE_INPUT_GRAD, G.RECOMPUTE_MIN_POINTS = recompute, 0
+        enc.embeddings.requires_grad_(not frozen)
+        enc.embeddings.grad = None
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+            y = enc(xi, bound=1)
+        y.backward(gout.to(y.dtype))
+        return y.detach(), xi.grad, None if frozen else enc.embeddings.grad.clone()
+
+    try:
+        for frozen in (True, False):
+            y0, g0, t0 = run(False, frozen)
+            y1, g1, t1 = run(True, frozen)
+            assert torch.equal(y0, y1) and torch.equal(g0, g1) and g0.abs().max() > 0
+            outside = ((x < -1) | (x > 1)).any(dim=-1)
+            assert outside.sum() > 100 and (g1[outside] == 0).all()
+            if not frozen:
+                # the same scatter both times; atomics make the sum order-dependent (half2 atomics round every partial sum)
+                assert (t0 - t1).abs().max() <= (5e-3 if half else 1e-5) * t0.abs().max()
+    finally:
+        G.RECOMPUTE_INPUT_GRAD, G.RECOMPUTE_MIN_POINTS = True, 32768
+        enc.embeddings.requires_grad_(True)
