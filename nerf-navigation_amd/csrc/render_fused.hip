@@ -30,9 +30,11 @@
 #include "ngp_camera.h"
 
 #ifndef RF_MIX_BLEND
-#define RF_MIX_BLEND 0                 // 1: blend products with v_fma_mix{lo,hi}_f16 -- NOT the reference arithmetic: the instruction rounds
-                                       // the exact product once to half (1,637 of 1.92 M image values of an 800x800 frame change, up to
-                                       // 7.5e-5; 3.97 vs 3.99 ms).  0: cvt / mul / cvt with the binary32 product kept (ngp_f2h).
+#define RF_MIX_BLEND 2                 // products of the trilinear blend, half(w * float(v)) with TWO roundings as in the reference:
+                                       //   0: cvt / v_pk_mul_f32 / cvt (ngp_f2h)                                          4.02-4.04 ms
+                                       //   2: v_fma_mix_f32 (binary32 product straight from the packed halves) + one cvt_pk: same bits, 3.87-3.88 ms
+                                       //   1: v_fma_mixlo/hi_f16 -- timing only, NOT the reference arithmetic: it rounds the exact product
+                                       //      once (1,637 of the 1.92 M values of an 800x800 image differ by up to 7.5e-5)  3.95-3.97 ms
 #endif
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
@@ -225,9 +227,10 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
 
 // Blend of one level.  Reference arithmetic per corner and feature (gridencoder.cu:147-166, scalar_t = at::Half):
 //   w = (wx * wy) * wz in binary32;  results[ch] += w * grid[...]  ==  half(float(result) + float(half(w * float(v))))
-// The product is rounded to binary32 and then to binary16 (ngp_f2h); v_fma_mixlo/mixhi_f16 would do it in one instruction
-// per feature but round only once (RF_MIX_BLEND, kept as a timing-only build).  The packed-half add is the correctly
-// rounded binary16 sum.
+// The product is rounded to binary32 (v_fma_mix_f32: fma32(w, float(v), +0) reads the half straight out of the packed row)
+// and then to binary16 by the packed conversion; the +0 addend only turns a -0 product into +0, which a sum that starts at
+// +0 cannot tell apart.  v_fma_mixlo/mixhi_f16 would do both steps in one instruction but round only once (RF_MIX_BLEND 1,
+// timing only).  The packed-half add is the correctly rounded binary16 sum.
 __device__ __forceinline__ void rf_blend_pair(const rf_pair& in, int h, ngp_h8& out) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -241,11 +244,19 @@ __device__ __forceinline__ void rf_blend_pair(const rf_pair& in, int h, ngp_h8& 
         #pragma unroll
         for (int c = 0; c < 8; c++) {
             const float wc = w[c >> 1][c & 1];
-#if RF_MIX_BLEND
+#if RF_MIX_BLEND == 1
             uint32_t prod;
             asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(prod) : "v"(wc), "v"(in.raw[j][c]));
             asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(prod) : "v"(wc), "v"(in.raw[j][c]));
             acc = acc + __builtin_bit_cast(h2, prod);
+#elif RF_MIX_BLEND == 2
+            // binary32 products straight from the packed halves (v_fma_mix_f32 = fma32(w, float(v), +0), rounded to binary32),
+            // then ONE packed conversion: the reference's two roundings in 3 instructions instead of 5
+            float p0, p1;
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(p0) : "v"(wc), "v"(in.raw[j][c]));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(p1) : "v"(wc), "v"(in.raw[j][c]));
+            const h2 prod = {(_Float16)p0, (_Float16)p1};
+            acc = acc + prod;
 #else
             const h2 v = __builtin_bit_cast(h2, in.raw[j][c]);
             const h2 prod = {ngp_f2h(wc * (float)v.x), ngp_f2h(wc * (float)v.y)};
