@@ -98,3 +98,64 @@ class NavQueries:
 
     def get_rays_fn(self, pose):
         return get_rays(pose, self.intrinsics, self.H, self.W)
+
+
+class _GraphedPointwise(torch.autograd.Function):
+    """sigma = f(x) for a point-wise f whose value AND per-point gradient were produced by one graph replay: the backward is
+    grad_x[i] = grad_sigma[i] * dsigma_i/dx_i (a point's density depends on that point only)."""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        sigma, jac = owner._replay(x)
+        ctx.save_for_backward(jac)
+        return sigma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable          # like the reference's encoder backward: no second derivative
+    def backward(ctx, grad_sigma):
+        (jac,) = ctx.saved_tensors
+        return grad_sigma.reshape(-1, 1) * jac, None
+
+
+class GraphedDensity:
+    """The planner's query (`density_fn` on a fixed number of body points + its gradient, nav/quad_plot.py:224-250) is
+    launch-bound: ~15 kernels of a few microseconds each.  This captures value and per-point gradient into ONE hipGraph
+    (torch.cuda.CUDAGraph) and replays it per call; the returned sigma is differentiable w.r.t. the points through the
+    captured per-point gradient.  Same kernels and the same sigma bits as `NavQueries.density_fn`; the gradient is bit-identical
+    for a plain sum and equal to rounding when the caller weights the densities; the model must stay frozen
+    and unchanged while the graph is in use (re-create the object after loading new weights).
+
+        dens = GraphedDensity(queries, n_points=10000)
+        sigma = dens(x)                 # x [..., 3] with prod(shape[:-1]) == n_points; sigma.sum().backward() works
+    """
+
+    def __init__(self, queries, n_points, device=None):
+        self.q = queries
+        device = device or next(queries.renderer.parameters()).device
+        if any(p.requires_grad for p in queries.renderer.parameters()):
+            raise ValueError("GraphedDensity needs a frozen model (NavQueries(freeze=True))")
+        self.n = int(n_points)
+        self._x = torch.zeros(self.n, 3, device=device, requires_grad=True)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                       # warm-up outside the capture (lazy initialisation, allocator)
+            for _ in range(2):
+                s = self.q.density_fn(self._x)
+                torch.autograd.grad(s.sum(), self._x)
+        torch.cuda.current_stream(device).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._sigma = self.q.density_fn(self._x)
+            (self._jac,) = torch.autograd.grad(self._sigma.sum(), self._x)
+
+    def _replay(self, x):
+        with torch.no_grad():
+            self._x.copy_(x.reshape(self.n, 3))
+        self._graph.replay()
+        return self._sigma.clone(), self._jac.clone()        # the static buffers are overwritten by the next replay
+
+    def __call__(self, x):
+        if x.numel() != 3 * self.n:
+            raise ValueError(f"GraphedDensity was captured for {self.n} points, got {x.numel() // 3}")
+        flat = x.reshape(self.n, 3)
+        return _GraphedPointwise.apply(flat, self).reshape(x.shape[:-1])

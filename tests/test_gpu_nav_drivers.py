@@ -75,3 +75,38 @@ def test_frozen_nav_queries_equal_the_trainable_ones(dev):
     ib.sum().backward()
     assert ia.shape == (1, 1024, 3) and torch.equal(ia, ib)
     assert torch.equal(oa.grad, ob.grad) and torch.equal(da.grad, db.grad)
+
+
+def test_graphed_density_matches_eager_bit_for_bit(dev):
+    """ngp.nav.GraphedDensity: the planner's density query and its gradient as one graph replay.  Values equal the eager
+    `density_fn` exactly; gradients exactly for a plain sum and to rounding under a weighted one; two sets of points."""
+    from ngp import nav, workload as W
+    from ngp.field import NGPField
+    from ngp.render import NGPRenderer
+    torch.manual_seed(1)
+    field = NGPField(bound=W.BOUND).to(dev)
+    with torch.no_grad():
+        field.encoder.embeddings.uniform_(-0.5, 0.5)
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=False).to(dev).eval()
+    q = nav.NavQueries(ren, W.intrinsics(32, 32), 32, 32)
+    dens = nav.GraphedDensity(q, n_points=20 * 500)
+    for seed in (0, 1):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        pts = torch.rand(20, 500, 3, device=dev, generator=g) * 2 - 1
+        wts = torch.rand(20, 500, device=dev, generator=g)
+        a = pts.clone().requires_grad_(True)
+        sa = q.density_fn(a)
+        (sa * wts).sum().backward()
+        b = pts.clone().requires_grad_(True)
+        sb = dens(b)
+        (sb * wts).sum().backward()
+        assert sb.shape == (20, 500) and torch.equal(sa, sb) and a.grad.abs().max() > 0
+        # a weighted sum scales the captured per-point gradient afterwards instead of feeding the weight through the chain:
+        # the same number up to binary32 rounding along the chain (sums of 64 products in another order)
+        assert (a.grad - b.grad).abs().max() <= 1e-5 * a.grad.abs().max()
+        a2, b2 = pts.clone().requires_grad_(True), pts.clone().requires_grad_(True)
+        q.density_fn(a2).sum().backward()
+        dens(b2).sum().backward()
+        assert torch.equal(a2.grad, b2.grad)                  # unit upstream gradient (the planner's plain sum): bit for bit
+    with pytest.raises(ValueError):
+        dens(torch.zeros(7, 3, device=dev))

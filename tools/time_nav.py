@@ -54,3 +54,8 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
         filt()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
+dens = nav.GraphedDensity(q, n_points=pts.numel() // 3)
+def planner_graphed():
+    p = pts.clone().requires_grad_(True)
+    dens(p).sum().backward()
+print("frozen model, one graph replay per planner query: (ii) %.3f ms" % timeit(planner_graphed, 200))
