@@ -379,6 +379,9 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_S
 #define RV_S 12                        // samples each lane may march per round (k_render_frame_multi); 1 = k_render_frame
 #endif
+#ifndef RV_SORT_COLUMNS
+#define RV_SORT_COLUMNS 1      // 1: tile columns taken in order of decreasing sample count (fewer dummy columns), 0: lane order
+#endif
 #ifndef RV_XCD_QUEUES
 #define RV_XCD_QUEUES 1        // 1: eight ray queues, one per XCD (image bands), with stealing; 0: one global queue
 #endif
@@ -1227,9 +1230,31 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             }
         }
 #else
+#if RV_SORT_COLUMNS
+        // Tile columns in order of decreasing sample count: lane group p evaluates the rays ranked 16p .. 16p+15, so the rays
+        // of a group hold about the same number of samples and few columns of its tiles are dummies (a group runs
+        // max-count tiles).  Counting sort over the 0..RV_S possible counts with ballots; `col_src` = the lane whose samples
+        // column r evaluates.  Any assignment of rays to columns gives the same values (columns are independent).
+        int col_src;
+        {
+            uint32_t rank = 0, above = 0;
+            const uint32_t below_me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id
+            #pragma unroll
+            for (int c = RV_S; c >= 0; c--) {
+                const unsigned long long mc = __ballot(cnt == c);
+                if (cnt == c) rank = above + (uint32_t)__popcll(mc & ((1ull << below_me) - 1ull));
+                above += (uint32_t)__popcll(mc);
+            }
+            col_src = __builtin_amdgcn_ds_permute((int)(rank << 2), (int)below_me);
+        }
+#endif
         #pragma unroll 1
         for (int p = 0; p < 4; p++) {
+#if RV_SORT_COLUMNS
+            const int src = __shfl(col_src, 16 * p + s, 64);
+#else
             const int src = 16 * p + s;
+#endif
             const int ccol = __shfl(cnt, src, 64);
             if (__ballot(ccol > 0) == 0ull) continue;
             const ngp_h4 shq = *reinterpret_cast<const ngp_h4*>(wave_sh + src * 16 + 4 * g);
