@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     rv_block_cache bc;                                 // bitfield word of the block the ray last tested (block ids are global: stays valid across rays)
     uint32_t n_samples_local = 0, n_tiles = 0, n_capped_local = 0, n_hit_local = 0;
 #ifdef RV_COUNTERS
-    uint32_t n_rounds = 0, n_trips = 0, n_probe[3] = {0, 0, 0};
+    uint32_t n_rounds = 0, n_trips = 0, n_probe[4] = {0, 0, 0, 0};   // [3]: samples evaluated behind a ray's last one
     unsigned long long c_refill = 0, c_march = 0, c_tiles = 0, c_comp = 0;
     const unsigned long long c_start = __builtin_readcyclecounter();
     unsigned long long c_last = c_start;
@@ -1341,7 +1341,13 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             tcomp += d1;
             dacc += w * tcomp;
             cr += w * sr; cg += w * sg; cb += w * sb;
-            if ((double)T < 1e-4) { done = true; break; }    // samples marched beyond this one are discarded
+            if ((double)T < 1e-4) {                          // samples marched beyond this one are discarded
+                done = true;
+#ifdef RV_COUNTERS
+                n_probe[3] += (uint32_t)(cnt - (k + 1));
+#endif
+                break;
+            }
         }
         const bool capped = !done && ended && nsamp >= F.max_steps && t < far;
         if (ended) done = true;
@@ -1390,7 +1396,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     if (lane == 0 && n_tiles) atomicAdd(F.stats + 3, n_tiles);
 #ifdef RV_COUNTERS
     if (lane == 0) { atomicAdd(F.queue + 1, n_rounds); atomicAdd(F.queue + 2, n_trips); }
-    atomicAdd(F.queue + 3, n_probe[0]); atomicAdd(F.queue + 4, n_probe[1]); atomicAdd(F.queue + 5, n_probe[2]);
+    atomicAdd(F.queue + 3, n_probe[0]); atomicAdd(F.queue + 4, n_probe[1]); atomicAdd(F.queue + 5, n_probe[2]); atomicAdd(F.queue + 6, n_probe[3]);
     if (lane == 0) {                                   // cycle counters: u64 at bytes 32.. of the workspace header
         unsigned long long* c = reinterpret_cast<unsigned long long*>(F.queue + 8);
         const unsigned long long c_total = __builtin_readcyclecounter() - c_start;

@@ -32,7 +32,7 @@ print("samples", st[0], "rays with samples", st[2], "tiles", st[3], "fill %.3f" 
 if ws[1]:
     print("wave rounds", ws[1], "march trips", ws[2], "tiles/round %.2f" % (st[3] / ws[1]), "trips/round %.2f" % (ws[2] / ws[1]),
           "samples/round %.1f" % (st[0] / ws[1]))
-    print("lane probes: fine-tested", ws[3], "(of which samples", st[0], ") coarse-empty", ws[4], "super-empty", ws[5])
+    print("lane probes: fine-tested", ws[3], "(of which samples", st[0], ") coarse-empty", ws[4], "super-empty", ws[5], "; samples evaluated behind a terminated ray:", ws[6])
 
     c = out["workspace"][32:88].view(torch.int64).cpu().numpy().view(np.uint64)
     nw = 2048.0                                             # 256 workgroups x 8 waves
