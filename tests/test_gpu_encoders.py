@@ -172,6 +172,51 @@ def test_sh_encoder_forward_backward(dev, degree):
     assert not y2.requires_grad
 
 
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_encoder_against_the_reference_polynomial_table(dev, degree):
+    """Golden: the reference's own 64 + 192 polynomials (shencoder/src/shencoder.cu:50-355) evaluated in float64 from their text
+    (tests/golden/make_sh_golden.py).  The HIP kernel uses float32 recurrences: tolerance 2e-6 of the largest term for the outputs,
+    3e-5 of the largest input gradient for the backward (sum of up to 64 float32 products)."""
+    import os
+    from shencoder import SHEncoder
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sh_deg8.npz"))
+    v, C2 = z["inputs"], degree * degree
+    ref, jac = z["outputs"][:, :C2], z["dy_dx"][:, :, :C2]
+    enc = SHEncoder(degree=degree)
+    tv = t(v, dev).requires_grad_(True)
+    y = enc(tv)
+    assert np.max(np.abs(y.detach().cpu().numpy() - ref)) < 2e-6 * max(1.0, float(np.abs(ref).max()))
+    rng = np.random.default_rng(degree)
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    y.backward(t(g, dev))
+    gi_ref = np.einsum("bc,bdc->bd", g.astype(np.float64), jac)              # shencoder.cu:359-383
+    assert np.max(np.abs(tv.grad.cpu().numpy() - gi_ref)) < 3e-5 * max(1.0, float(np.abs(gi_ref).max()))
+
+
+def test_trunc_exp_product_against_reference_golden(dev):
+    """T1: ngp.field.trunc_exp (the product's activation, activation.py:5-18) forward and backward on the GPU against the vectors the
+    reference's own module produced (tests/golden/trunc_exp.npz, incl. +-15.0001, 88, -104).  float32 exp of two libms: 2 ulp."""
+    import os
+    from ngp.field import trunc_exp
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "trunc_exp.npz"))
+    x, g, y_ref, dx_ref = z["x"], z["g"], z["y"], z["dx"]
+    xt = t(x, dev).requires_grad_(True)
+    y = trunc_exp(xt)
+    y.backward(t(g, dev))
+    y, dx = y.detach().cpu().numpy(), xt.grad.cpu().numpy()
+    fin = np.isfinite(y_ref)
+    assert np.array_equal(np.isfinite(y), fin)                               # exp(88) finite, overflow to inf at the same inputs
+    assert np.max(np.abs(y[fin] - y_ref[fin]) / np.maximum(y_ref[fin], 1e-45)) < 2.5e-7
+    assert np.max(np.abs(dx - dx_ref) / np.maximum(np.abs(dx_ref), 1e-30)) < 5e-7
+    # the clamp: beyond +-15 the gradient is g * exp(+-15) exactly as in the reference, not g * y
+    far = np.abs(x) > 15
+    assert far.sum() > 5 and np.allclose(dx[far], g[far] * np.exp(np.clip(x[far], -15, 15)), rtol=5e-7)
+    # under autocast the input is cast to float32 first (custom_fwd(cast_inputs=float32), activation.py:7)
+    with torch.autocast("cuda", dtype=torch.float16):
+        yh = trunc_exp(t(x[:64], dev).half())
+    assert yh.dtype == torch.float32
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # freqencoder (optional fifth module)
 # ---------------------------------------------------------------------------------------------------------------------

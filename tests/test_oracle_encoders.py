@@ -149,6 +149,19 @@ def test_sh_matches_reference_polynomials_and_finite_differences():
     assert np.max(np.abs(G - np.eye(16))) < 0.03
 
 
+def test_sh_oracle_equals_all_256_reference_polynomials():
+    """tests/golden/sh_deg8.npz = the 64 outputs and 192 partial derivatives of shencoder/src/shencoder.cu:50-355, read as text and
+    evaluated in float64 by tests/golden/make_sh_golden.py: the oracle's Legendre-derived basis must BE that table."""
+    z = np.load(os.path.join(GOLDEN, "sh_deg8.npz"))
+    v = z["inputs"].astype(np.float64)
+    for degree in range(1, 9):
+        out, jac = sh_oracle.sh_encode(v, degree, True)
+        C2 = degree * degree
+        jac = jac.reshape(-1, 3, C2)
+        assert np.max(np.abs(out - z["outputs"][:, :C2])) < 1e-12 * max(1.0, np.abs(z["outputs"][:, :C2]).max())
+        assert np.max(np.abs(jac - z["dy_dx"][:, :, :C2])) < 1e-12 * max(1.0, np.abs(z["dy_dx"][:, :, :C2]).max())
+
+
 def test_ffmlp_oracle_vs_torch_linear(oracle):
     rng = np.random.default_rng(0)
     for input_dim, num_layers in ((32, 2), (32, 3), (64, 2)):
