@@ -118,6 +118,38 @@ int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* density-grid maintenance.  Reference: nerf/renderer.py:381-537 -- Python loops over torch ops      */
+/* (meshgrid, morton3D, rand_like, density query, indexed scatter, masked EMA, mean, packbits); no native surface.   */
+/* ------------------------------------------------------------------------ */
+
+/* Sample points of one sweep: full (iter_density < 16, :455-483) = cascade * H^3 points, point e IS cell e of the
+ * [cascade][H^3] Morton-ordered grid; partial (:486-511) = per cascade H^3/4 uniformly random cells followed by H^3/4 picks
+ * among the cells with density_grid > 0 (ascending list, as torch.nonzero), 2 * (H^3/4) points per cascade. */
+uint32_t ngp_density_grid_points(uint32_t cascade, uint32_t H, int partial);
+size_t ngp_density_grid_workspace(uint32_t cascade, uint32_t H);
+
+/* nerf/renderer.py:473-483 / :488-507.  xyzs [n,3] f32 out (n = ngp_density_grid_points); cells [n] i32 out (partial sweep only;
+ * cascade * H^3 + Morton index, -1 = no sample because the cascade has no occupied cell); density_grid [cascade*H^3] f32 is read
+ * by the partial sweep only.  Random numbers: pcg32(seed, seq = iteration) (raymarching/src/pcg32.h), sample e owns draws
+ * [16 e, 16 e + 16): full sweep 0..2 jitter; partial sweep (e = cas * H^3/4 + i) 0..2 random cell (next_uint * H >> 32),
+ * 3 pick (next_uint * n_occ >> 32), 4..6 jitter of the random cell, 7..9 jitter of the picked cell. */
+int ngp_density_grid_sample(const float* density_grid, uint32_t cascade, uint32_t H, float bound, int partial, uint64_t seed,
+                            uint64_t iteration, float* xyzs, int32_t* cells, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nerf/renderer.py:511-531: tmp_grid[cells] = sigmas * density_scale (several samples of one cell: the largest);
+ * where density_grid >= 0 and tmp_grid >= 0: density_grid = max(density_grid * decay, tmp_grid); mean_density[0] =
+ * mean(clamp(density_grid, 0)) (summed in double in a fixed order); bitfield = packbits(density_grid, min(mean_density,
+ * density_thresh)).  cells == NULL: full sweep, sigmas [cascade*H^3] already in grid order.  mean_density: [1] f32 device. */
+int ngp_density_grid_update(const float* sigmas, const int32_t* cells, uint32_t n_points, float density_scale, float decay,
+                            float density_thresh, uint32_t cascade, uint32_t H, float* density_grid, uint8_t* bitfield,
+                            float* mean_density, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nerf/renderer.py:381-442: density_grid = -1 in every cell whose centre no camera sees (z > 0, |x| < cx/fx z + 2 half cells,
+ * same for y).  poses [B,4,4] f32 row-major camera-to-world on the DEVICE. */
+int ngp_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t cascade, uint32_t H,
+                            float bound, float* density_grid, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* _gridencoder  (reference: gridencoder/src/gridencoder.h:12-13)            */
 /* ------------------------------------------------------------------------ */
 

@@ -27,6 +27,15 @@ def read_checkpoint(path):
     return blob["model"] if isinstance(blob, dict) and "model" in blob else blob
 
 
+def read_checkpoint_full(path):
+    """-> (model state dict, extra): `extra` holds the scalars the reference's Trainer.save_checkpoint stores beside the model
+    (nerf/utils.py:944-953) and load_checkpoint restores into it (:1018-1022): mean_count, mean_density, epoch, global_step."""
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(blob, dict) and "model" in blob:
+        return blob["model"], {k: blob[k] for k in ("mean_count", "mean_density", "epoch", "global_step") if k in blob}
+    return blob, {}
+
+
 def split_state_dict(sd):
     """-> (field state dict, renderer buffers) of a reference model state dict."""
     field, ren = {}, {}
@@ -96,14 +105,21 @@ def field_from_state_dict(field_sd, bound, density_scale=1, fused=True):
     return field
 
 
-def load_renderer_buffers(renderer, ren_sd):
-    """density grid / bitfield / aabbs / step counter of a reference checkpoint into an NGPRenderer."""
+def load_renderer_buffers(renderer, ren_sd, extra=None):
+    """density grid / bitfield / aabbs / step counter of a reference checkpoint into an NGPRenderer.  `extra` (read_checkpoint_full)
+    restores mean_count / mean_density as the reference's load_checkpoint does: 'best' checkpoints drop density_grid, and without the
+    stored scalars a resumed run would allocate N * max_steps samples for 16 steps and threshold its first grid refresh at 0."""
     with torch.no_grad():
         for k, v in ren_sd.items():
             if hasattr(renderer, k) and getattr(renderer, k) is not None and torch.is_tensor(getattr(renderer, k)):
                 getattr(renderer, k).copy_(v.to(getattr(renderer, k).dtype))
     if "density_grid" in ren_sd:
         renderer.mean_density = float(torch.mean(renderer.density_grid.clamp(min=0)))
+    if extra:
+        if "mean_count" in extra:
+            renderer.mean_count = int(extra["mean_count"])
+        if "mean_density" in extra:
+            renderer.mean_density = float(extra["mean_density"])
 
 
 def to_reference_state_dict(renderer):

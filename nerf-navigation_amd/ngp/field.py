@@ -121,29 +121,54 @@ class NGPFieldFF(nn.Module):
         self._fused = None
         return self
 
-    def fused_state(self):
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .half() / .float() / .cuda(i) replace parameter storage without bumping _version: drop the fused half copies
+        self._fused = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _check_fused_shape(self):
+        """The one-launch kernels (csrc/render_fused.hip) are specialised for the reference's default field: 16 levels x 2 features of a
+        3-D hash grid, density net 32-64-64-16, colour net 32-64-64-64-16.  Any other shape would be misread silently: refuse it."""
+        e, sn, cn = self.encoder, self.sigma_net, self.color_net
+        ok = (e.num_levels == 16 and e.level_dim == 2 and e.input_dim == 3 and e.gridtype == "hash" and not e.align_corners
+              and sn.hidden_dim == 64 and cn.hidden_dim == 64 and sn.num_layers == 2 and cn.num_layers == 3
+              and sn.input_dim == 32 and cn.input_dim == 32 and self.geo_feat_dim == 15
+              and sn.weights.numel() == 7168 and cn.weights.numel() == 11264)
+        if not ok:
+            raise RuntimeError("the fused path supports the default field only (hash grid 16 x 2, FFMLP 32-64-64-16 and 32-64-64-64-16); "
+                               "use the per-op path (run_cuda / forward) for this configuration")
+
+    def fused_state(self, density_scale=None):
         """Half copies of table and weights plus the ngp_field_t describing them (include/ngp_hip.h).  The reference
         converts the table to half on EVERY forward under autocast (gridencoder/grid.py:38-39: a 50 MB read + 25 MB
-        write per call); the fused path keeps the half table resident and rebuilds it only when parameters change."""
-        key = (self.encoder.embeddings._version, self.sigma_net.weights._version, self.color_net.weights._version)
+        write per call); the fused path keeps the half table resident and rebuilds it only when parameters change.
+        density_scale: the renderer's (nerf/renderer.py:64 owns the one density_scale); default the field's own."""
+        self._check_fused_shape()
+        scale = float(self.density_scale if density_scale is None else density_scale)
+        emb_p = self.encoder.embeddings
+        key = (emb_p._version, self.sigma_net.weights._version, self.color_net.weights._version, emb_p.data_ptr(), str(emb_p.device),
+               self.sigma_net.weights.data_ptr(), self.color_net.weights.data_ptr(), self.encoder.offsets.data_ptr(), float(self.bound))
         if self._fused is None or self._fused["key"] != key:
-            emb = self.encoder.embeddings.detach().to(torch.half).contiguous()
+            emb = emb_p.detach().to(torch.half).contiguous()
             ws = self.sigma_net.weights.detach().to(torch.half).contiguous()
             wc = self.color_net.weights.detach().to(torch.half).contiguous()
-            f = _hip.ngp_field_t(emb.data_ptr(), self.encoder.offsets.data_ptr(), ws.data_ptr(), wc.data_ptr(),
-                                 self.encoder.num_levels, self.encoder.base_resolution,
-                                 float(np.log2(self.encoder.per_level_scale)), float(self.bound), float(self.density_scale))
-            self._fused = {"key": key, "tensors": (emb, ws, wc), "struct": f}
-        return self._fused["struct"]
+            self._fused = {"key": key, "tensors": (emb, ws, wc), "structs": {}}
+        st = self._fused["structs"]
+        if scale not in st:
+            emb, ws, wc = self._fused["tensors"]
+            st[scale] = _hip.ngp_field_t(emb.data_ptr(), self.encoder.offsets.data_ptr(), ws.data_ptr(), wc.data_ptr(),
+                                         self.encoder.num_levels, self.encoder.base_resolution,
+                                         float(np.log2(self.encoder.per_level_scale)), float(self.bound), scale)
+        return st[scale]
 
     @torch.no_grad()
-    def forward_fused(self, x, d):
+    def forward_fused(self, x, d, density_scale=None):
         """sigma (already times density_scale) and rgb for [M,3] points / directions in one launch (float32 out)."""
         x, d = x.contiguous().float(), d.contiguous().float()
         M = x.shape[0]
         sig = torch.empty(M, dtype=torch.float32, device=x.device)
         rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
-        f = self.fused_state()
+        f = self.fused_state(density_scale)
         _hip.check(_hip.lib().ngp_field_forward(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb),
                                                 _hip.stream()), "field_forward")
         return sig, rgb

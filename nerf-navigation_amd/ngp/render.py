@@ -5,7 +5,8 @@ Three render paths:
                      what a torch-ngp caller gets from the drop-in packages;
   render_fused(...)  one launch per frame (csrc/render_fused.hip) -- the MI355X-native fast path for inference;
   run(...)           the fixed-step path used by the nav loop (nerf/renderer.py:125-254, simulate.py:163-166).
-plus update_extra_state / mark_untrained_grid (density-grid maintenance, nerf/renderer.py:381-537).
+plus update_extra_state / mark_untrained_grid (density-grid maintenance, nerf/renderer.py:381-537) on the native ops of
+csrc/density_grid.hip.
 """
 import ctypes
 import math
@@ -18,9 +19,31 @@ import ngp_hip as _hip
 import raymarching
 
 
+def sample_pdf(bins, weights, n_samples, det=False, generator=None):
+    """nerf/renderer.py:12-46: draw n_samples per ray from the piecewise-constant pdf `weights` [B, T-1] over the intervals of
+    `bins` [B, T] by inverting its CDF; det=True uses the midpoints of n_samples equal probability slices."""
+    pdf = weights + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=cdf.device).expand(cdf.shape[0], n_samples)
+    else:
+        u = torch.rand(cdf.shape[0], n_samples, device=cdf.device, generator=generator)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b_lo, b_hi = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)
+
+
 class NGPRenderer(nn.Module):
     def __init__(self, field, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.01, grid_size=128):
         super().__init__()
+        self._mean_host, self._mean_dev = 0, None
         self.field = field
         self.bound = bound
         self.cascade = 1 + math.ceil(math.log2(bound))
@@ -37,6 +60,8 @@ class NGPRenderer(nn.Module):
             self.register_buffer("density_grid", torch.zeros([self.cascade, grid_size ** 3]))
             self.register_buffer("density_bitfield", torch.zeros(self.cascade * grid_size ** 3 // 8, dtype=torch.uint8))
             self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+            self.grid_seed = 0                             # pcg32 seed of the density-grid refresh (same on every replica)
+            self._grid_ws = None
             self.mean_density = 0
             self.iter_density = 0
             self.mean_count = 0
@@ -108,8 +133,8 @@ class NGPRenderer(nn.Module):
                                                             128, perturb, dt_gamma, max_steps)
                 if fused_field:
                     # the reference's loop and schedule, but encoder + both MLPs + activations in ONE launch per iteration
-                    # (ngp_field_forward: sigma already times the field's density_scale) instead of ~25 small ones
-                    sigmas, rgbs = self.field.forward_fused(xyzs, dirs)
+                    # (ngp_field_forward: sigma already times the renderer's density_scale) instead of ~25 small ones
+                    sigmas, rgbs = self.field.forward_fused(xyzs, dirs, density_scale=self.density_scale)
                 else:
                     sigmas, rgbs = self(xyzs, dirs)
                     sigmas = self.density_scale * sigmas
@@ -151,7 +176,7 @@ class NGPRenderer(nn.Module):
         aabb = (ctypes.c_float * 6)(*[float(v) for v in self._aabb().tolist()])
         L = _hip.lib()
         ws = _hip.workspace(L.ngp_render_frame_workspace(N), device)
-        f = self.field.fused_state()
+        f = self.field.fused_state(self.density_scale)
         _hip.check(L.ngp_render_frame(ctypes.byref(f), _hip.ptr(rays_o), _hip.ptr(rays_d), N, int(image_width), aabb, self.min_near,
                                       _hip.ptr(self.density_bitfield), self.cascade, self.grid_size, dt_gamma, max_steps, bg,
                                       _hip.ptr(image), _hip.ptr(depth), _hip.ptr(weights_sum), _hip.ptr(stats),
@@ -179,7 +204,7 @@ class NGPRenderer(nn.Module):
         pose_h, intr_h = _hip.camera_args(pose, intrinsics)
         L = _hip.lib()
         ws = _hip.workspace(L.ngp_render_frame_workspace(N), device)
-        f = self.field.fused_state()
+        f = self.field.fused_state(self.density_scale)
         _hip.check(L.ngp_render_frame_camera(ctypes.byref(f), pose_h, intr_h, int(H), int(W), aabb, self.min_near,
                                              _hip.ptr(self.density_bitfield), self.cascade, self.grid_size, dt_gamma, max_steps, bg,
                                              _hip.ptr(image), _hip.ptr(depth), _hip.ptr(weights_sum), _hip.ptr(stats),
@@ -189,10 +214,17 @@ class NGPRenderer(nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     # fixed-step path (nav loop)
     # ------------------------------------------------------------------------------------------------------------
-    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=0, bg_color=None, perturb=False, **kwargs):
-        """nerf/renderer.py:125-254 with upsample_steps == 0 (the nav configuration, simulate.py:122-123)."""
-        if upsample_steps > 0:
-            raise NotImplementedError("upsample_steps > 0 (sample_pdf) is not on the navigation path")
+    def _ray_weights(self, z_vals, sample_dist, sigma):
+        """nerf/renderer.py:206-210: alpha compositing weights of sorted samples; the last interval is `sample_dist` long"""
+        deltas = torch.cat([z_vals[..., 1:] - z_vals[..., :-1], sample_dist * torch.ones_like(z_vals[..., :1])], dim=-1)
+        alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+        trans = torch.cumprod(torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1), dim=-1)[..., :-1]
+        return alphas * trans, deltas
+
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, generator=None, **kwargs):
+        """nerf/renderer.py:125-254: fixed-step sampling between the AABB hits, optional importance resampling (sample_pdf), torch
+        compositing.  The nav loop calls it with num_steps=512, upsample_steps=0 (simulate.py:122-123); the default 128 + 128 is the
+        reference's.  `generator` seeds perturb / the training-mode resampling (the reference uses the global RNG)."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -206,25 +238,33 @@ class NGPRenderer(nn.Module):
         z_vals = nears + (fars - nears) * z_vals
         sample_dist = (fars - nears) / num_steps
         if perturb:
-            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
-        xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
-        xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device, generator=generator) - 0.5) * sample_dist
 
-        density_outputs = self.density(xyzs.reshape(-1, 3))
-        for k, v in density_outputs.items():
-            density_outputs[k] = v.view(N, num_steps, -1)
+        def points(z):
+            p = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+            return torch.min(torch.max(p, aabb[:3]), aabb[3:])
 
-        deltas = z_vals[..., 1:] - z_vals[..., :-1]
-        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
-        alphas = 1 - torch.exp(-deltas * self.density_scale * density_outputs["sigma"].squeeze(-1))
-        alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
-        weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
+        xyzs = points(z_vals)
+        dens = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
 
+        if upsample_steps > 0:
+            with torch.no_grad():
+                w, deltas = self._ray_weights(z_vals, sample_dist, dens["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(z_mid, w[:, 1:-1], upsample_steps, det=not self.training, generator=generator).detach()
+                new_xyzs = points(new_z)
+            new_dens = {k: v.view(N, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3)).items()}
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.gather(torch.cat([xyzs, new_xyzs], dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 3))
+            for k in dens:
+                both = torch.cat([dens[k], new_dens[k]], dim=1)
+                dens[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+
+        weights, _ = self._ray_weights(z_vals, sample_dist, dens["sigma"].squeeze(-1))
         dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
-        for k, v in density_outputs.items():
-            density_outputs[k] = v.view(-1, v.shape[-1])
+        flat = {k: v.reshape(-1, v.shape[-1]) for k, v in dens.items()}
         mask = weights > 1e-4
-        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **density_outputs).view(N, -1, 3)
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **flat).view(N, -1, 3)
 
         weights_sum = weights.sum(dim=-1)
         ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
@@ -263,55 +303,58 @@ class NGPRenderer(nn.Module):
         self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
         return thresh
 
+    # mean_density lives on the device after a native grid refresh; the host value is fetched only when somebody asks for it
+    @property
+    def mean_density(self):
+        if self._mean_dev is not None:
+            self._mean_host = float(self._mean_dev.item())
+            self._mean_dev = None
+        return self._mean_host
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self._mean_host = value
+        self._mean_dev = None
+
+    def _grid_workspace(self):
+        need = _hip.lib().ngp_density_grid_workspace(self.cascade, self.grid_size)
+        dev = self.density_bitfield.device
+        if self._grid_ws is None or self._grid_ws.numel() < need or self._grid_ws.device != dev:
+            self._grid_ws = _hip.workspace(need, dev)
+        return self._grid_ws
+
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128, generator=None):
-        """nerf/renderer.py:446-537.  `generator` seeds the jitter / sampling so replicas stay identical."""
+    def update_extra_state(self, decay=0.95, S=128, seed=None):
+        """nerf/renderer.py:446-537 on the native ops of csrc/density_grid.hip: sample points (full sweep for the first 16 calls,
+        then H^3/4 random + H^3/4 occupied cells per cascade) -> density query in chunks of S^3 points -> scatter / EMA / mean /
+        packbits on the device, no host synchronisation for the grid (mean_density stays on the device until it is read).
+        Random numbers come from pcg32(seed = self.grid_seed, stream = iter_density): identical on every replica."""
         if not self.cuda_ray:
             return
+        L = _hip.lib()
         dev = self.density_bitfield.device
-        H = self.grid_size
-        tmp_grid = -torch.ones_like(self.density_grid)
-
-        def rand_like(t):
-            return torch.rand(t.shape, device=dev, dtype=t.dtype, generator=generator)
-
-        def query(coords, indices, cas):
-            xyzs = 2 * coords.float() / (H - 1) - 1
-            bound = min(2 ** cas, self.bound)
-            half_grid_size = bound / H
-            cas_xyzs = xyzs * (bound - half_grid_size)
-            cas_xyzs += (rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-            sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach().float()
-            sigmas *= self.density_scale
-            tmp_grid[cas, indices] = sigmas
-
-        if self.iter_density < 16:
-            ar = torch.arange(H, dtype=torch.int32, device=dev).split(S)
-            for xs in ar:
-                for ys in ar:
-                    for zs in ar:
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        for cas in range(self.cascade):
-                            query(coords, indices, cas)
-        else:
-            N = H ** 3 // 4
-            for cas in range(self.cascade):
-                coords = torch.randint(0, H, (N, 3), device=dev, generator=generator)
-                indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev, generator=generator)
-                occ_indices = occ_indices[rand_mask]
-                occ_coords = raymarching.morton3D_invert(occ_indices)
-                query(torch.cat([coords, occ_coords], dim=0), torch.cat([indices, occ_indices], dim=0), cas)
-
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        cas, H = self.cascade, self.grid_size
+        partial = self.iter_density >= 16
+        seed = self.grid_seed if seed is None else seed
+        n = int(L.ngp_density_grid_points(cas, H, int(partial)))
+        ws = self._grid_workspace()
+        xyzs = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        cells = torch.empty(n, dtype=torch.int32, device=dev) if partial else None
+        grid = self.density_grid.view(-1)
+        with torch.cuda.device(dev):
+            _hip.check(L.ngp_density_grid_sample(_hip.ptr(grid), cas, H, float(self.bound), int(partial), int(seed), int(self.iter_density),
+                                                 _hip.ptr(xyzs), _hip.ptr(cells), _hip.ptr(ws), ws.numel(), _hip.stream()), "density_grid_sample")
+            sigmas = torch.empty(n, dtype=torch.float32, device=dev)
+            chunk = max(int(S), 1) ** 3
+            for head in range(0, n, chunk):
+                tail = min(head + chunk, n)
+                sigmas[head:tail] = self.density(xyzs[head:tail])["sigma"].reshape(-1).detach().float()
+            mean = torch.empty(1, dtype=torch.float32, device=dev)
+            _hip.check(L.ngp_density_grid_update(_hip.ptr(sigmas), _hip.ptr(cells), n, float(self.density_scale), float(decay),
+                                                 float(self.density_thresh), cas, H, _hip.ptr(grid), _hip.ptr(self.density_bitfield),
+                                                 _hip.ptr(mean), _hip.ptr(ws), ws.numel(), _hip.stream()), "density_grid_update")
+        self._mean_dev = mean
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
 
         total_step = min(16, self.local_step)
         if total_step > 0:
@@ -320,35 +363,15 @@ class NGPRenderer(nn.Module):
 
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        """nerf/renderer.py:381-442: cells no training camera sees get density -1."""
+        """nerf/renderer.py:381-442 as one launch (ngp_mark_untrained_grid): cells no training camera sees get density -1."""
         if not self.cuda_ray:
             return
         if isinstance(poses, np.ndarray):
             poses = torch.from_numpy(poses)
         dev = self.density_bitfield.device
-        H = self.grid_size
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
-        count = torch.zeros_like(self.density_grid)
-        poses = poses.to(dev)
-        ar = torch.arange(H, dtype=torch.int32, device=dev).split(S)
-        for xs in ar:
-            for ys in ar:
-                for zs in ar:
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    world_xyzs = (2 * coords.float() / (H - 1) - 1).unsqueeze(0)
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / H
-                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                        for head in range(0, B, S):
-                            tail = min(head + S, B)
-                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
-                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
-                            mask_z = cam_xyzs[:, :, 2] > 0
-                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            count[cas, indices] += (mask_z & mask_x & mask_y).sum(0).reshape(-1)
-        self.density_grid[count == 0] = -1
+        poses = poses.to(device=dev, dtype=torch.float32).reshape(-1, 4, 4).contiguous()
+        fx, fy, cx, cy = (float(v) for v in intrinsic)
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().ngp_mark_untrained_grid(_hip.ptr(poses), poses.shape[0], fx, fy, cx, cy, self.cascade, self.grid_size,
+                                                          float(self.bound), _hip.ptr(self.density_grid.view(-1)), _hip.stream()),
+                       "mark_untrained_grid")

@@ -67,16 +67,15 @@ class NGPTrainer:
         self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.exchange = GradExchange(list(renderer.field.parameters()))
         self.global_step = 0
-        dev = next(renderer.parameters()).device
-        # the same generator seed on every rank keeps the density grids of the replicas identical
-        self.grid_gen = torch.Generator(device=dev).manual_seed(seed)
+        # the same pcg32 seed on every rank keeps the density grids of the replicas identical
+        renderer.grid_seed = int(seed)
 
     def step(self, rays_o, rays_d, target, bg_color=1, **march):
         """One optimisation step on a [1, N, 3] ray batch; returns the (unscaled) loss as a tensor."""
         ren = self.ren.train()
         if self.global_step % self.update_extra_interval == 0:
             with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-                ren.update_extra_state(generator=self.grid_gen)
+                ren.update_extra_state()
         self.opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)

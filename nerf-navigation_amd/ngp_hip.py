@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 F32, F16 = 0, 1
 
 c_u32, c_f32, c_int, c_vp, c_sz = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+c_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/ngp_hip.h one to one
 _SIGNATURES = {
@@ -39,6 +40,11 @@ _SIGNATURES = {
     "ngp_composite_rays": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ngp_compact_alive_workspace": (c_sz, [c_u32]),
     "ngp_compact_alive": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_density_grid_points": (c_u32, [c_u32, c_u32, c_int]),
+    "ngp_density_grid_workspace": (c_sz, [c_u32, c_u32]),
+    "ngp_density_grid_sample": (c_int, [c_vp, c_u32, c_u32, c_f32, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_density_grid_update": (c_int, [c_vp, c_vp, c_u32, c_f32, c_f32, c_f32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_mark_untrained_grid": (c_int, [c_vp, c_u32, c_f32, c_f32, c_f32, c_f32, c_u32, c_u32, c_f32, c_vp, c_vp]),
     "ngp_grid_encode_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_int, c_vp,
                                         c_u32, c_int, c_int, c_vp]),
     "ngp_grid_encode_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_int,

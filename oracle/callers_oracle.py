@@ -148,7 +148,10 @@ class DefaultField:
     """NeRFNetwork of nerf/network.py: sigma net Linear(32,64), Linear(64,16); colour net Linear(31,64), Linear(64,64), Linear(64,3);
     no biases (:45,66).  Parameters are plain leaf tensors so tests read their .grad."""
 
-    def __init__(self, embeddings, offsets, per_level_scale, sigma_weights, color_weights, bound, dtype=torch.float32):
+    def __init__(self, embeddings, offsets, per_level_scale, sigma_weights, color_weights, bound, dtype=torch.float32, ff_layout=False):
+        """ff_layout: the FFMLP variant of nerf/network_ff.py:51-77 -- colour input cat(SH16, geo15, one zero column) = 32 wide (:67-68),
+        colour output 16 wide of which [:3] is used (:72-74); any number of hidden layers in either net."""
+        self.ff_layout = ff_layout
         as_t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype).clone().requires_grad_(True)        # noqa: E731
         self.embeddings = as_t(embeddings)
         self.offsets = [int(v) for v in offsets]
@@ -179,7 +182,10 @@ class DefaultField:
             if not mask.any():
                 return rgbs
             d, geo_feat = d[mask], geo_feat[mask]
-        h = torch.sigmoid(self._mlp(self.color_weights, torch.cat([sh_encode(d.to(self.dtype)), geo_feat], dim=-1)))
+        cin = [sh_encode(d.to(self.dtype)), geo_feat]
+        if self.ff_layout:
+            cin.append(torch.zeros_like(geo_feat[..., :1]))
+        h = torch.sigmoid(self._mlp(self.color_weights, torch.cat(cin, dim=-1))[..., :3])
         if mask is not None:
             rgbs = rgbs.clone()
             rgbs[mask] = h
@@ -349,9 +355,9 @@ def grid_sample_positions(coords, noise, cas, bound, H):
     """nerf/renderer.py:473-483 in binary32, one rounding per written operation: coords int [n,3], noise [n,3] in [0,1)."""
     f = np.float32
     xyzs = f(2) * coords.astype(f) / f(H - 1) - f(1)
-    b = f(min(2 ** cas, bound))
-    half = b / f(H)
-    return (xyzs * (b - half) + (noise.astype(f) * f(2) - f(1)) * half).astype(f)
+    b = float(min(2 ** cas, bound))
+    half, span = f(b / H), f(b - b / H)                                  # Python floats in the reference: double, then narrowed
+    return (xyzs * span + (noise.astype(f) * f(2) - f(1)) * half).astype(f)
 
 
 def update_extra_state(density_fn, density_grid, bound, density_thresh, iter_density, randoms, density_scale=1.0, decay=0.95, H=128):
@@ -401,7 +407,8 @@ def mark_untrained_grid(density_grid, poses, intrinsic, bound, H=128):
     """nerf/renderer.py:381-442: count, per cell and cascade, the cameras whose frustum holds the cell centre; 0 -> density -1.
     binary32 with one rounding per operation in the order csrc/density_grid.hip uses: ((p - t) . R[:,k]) summed x, y, z."""
     f = np.float32
-    fx, fy, cx, cy = (f(v) for v in intrinsic)
+    fx, fy, cx, cy = (float(v) for v in intrinsic)
+    tan_x, tan_y = f(cx / fx), f(cy / fy)                                 # Python floats in the reference (:432-433): double, then narrowed
     poses = np.asarray(poses, f)
     cascade = density_grid.shape[0]
     grid = np.array(density_grid, dtype=f)
@@ -409,14 +416,14 @@ def mark_untrained_grid(density_grid, poses, intrinsic, bound, H=128):
     coords = O.morton3D_invert(idx)
     world = f(2) * coords.astype(f) / f(H - 1) - f(1)
     for cas in range(cascade):
-        b = f(min(2 ** cas, bound))
-        half = b / f(H)
-        p = world * (b - half)
+        b = float(min(2 ** cas, bound))
+        half = f(b / H)
+        p = world * f(b - b / H)
         count = np.zeros(H ** 3, np.int64)
         for pose in poses:
             q = p - pose[:3, 3]
             cam = [(q[:, 0] * pose[0, k] + q[:, 1] * pose[1, k]) + q[:, 2] * pose[2, k] for k in range(3)]
-            ok = (cam[2] > 0) & (np.abs(cam[0]) < (cx / fx) * cam[2] + half * f(2)) & (np.abs(cam[1]) < (cy / fy) * cam[2] + half * f(2))
+            ok = (cam[2] > 0) & (np.abs(cam[0]) < tan_x * cam[2] + half * f(2)) & (np.abs(cam[1]) < tan_y * cam[2] + half * f(2))
             count += ok
         grid[cas, count == 0] = -1
     return grid

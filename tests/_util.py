@@ -38,3 +38,37 @@ def camera_rays(n_side=32, radius=3.0, seed=0, jitter=True):
     extra_o = np.array([[-3, 0.1, 0.2], [0.3, -3, 0.1], [0.2, 0.1, 3], [5, 5, 5]], np.float32)
     extra_d = np.array([[1, 0, 0], [0, 1, 0], [0, 0, -1], [1, 0, 0]], np.float32)
     return np.concatenate([o, extra_o]), np.concatenate([d, extra_d])
+
+
+def oracle_field(field, dtype=None):
+    """oracle.callers_oracle.DefaultField holding the parameters of a product field module (ngp.field.NGPField or NGPFieldFF):
+    the CPU checker the GPU parity tests compare against."""
+    import torch
+    from oracle import callers_oracle as CO
+    dtype = dtype or torch.float32
+    emb = field.encoder.embeddings.detach().float().cpu().numpy()
+    offsets = field.encoder.offsets.cpu().numpy()
+    pls = float(field.encoder.per_level_scale)
+    if hasattr(field.sigma_net, "weights"):                                   # FFMLP: flat [64,in] + k [64,64] + [16,64] (ffmlp/ffmlp.py:121-122)
+        def split(net):
+            w = net.weights.detach().float().cpu().numpy()
+            shapes = [(net.hidden_dim, net.input_dim)] + [(net.hidden_dim, net.hidden_dim)] * (net.num_layers - 1) + [(net.padded_output_dim, net.hidden_dim)]
+            out, off = [], 0
+            for r, c in shapes:
+                out.append(w[off:off + r * c].reshape(r, c)); off += r * c
+            assert off == w.size
+            return out
+        return CO.DefaultField(emb, offsets, pls, split(field.sigma_net), split(field.color_net), field.bound, dtype=dtype, ff_layout=True)
+    sw = [l.weight.detach().float().cpu().numpy() for l in field.sigma_net]
+    cw = [l.weight.detach().float().cpu().numpy() for l in field.color_net]
+    return CO.DefaultField(emb, offsets, pls, sw, cw, field.bound, dtype=dtype)
+
+
+def ff_grads_as_matrices(net):
+    """.grad of an FFMLP's flat weights as the list of per-layer matrices (same split as oracle_field)."""
+    g = net.weights.grad.detach().float().cpu().numpy()
+    shapes = [(net.hidden_dim, net.input_dim)] + [(net.hidden_dim, net.hidden_dim)] * (net.num_layers - 1) + [(net.padded_output_dim, net.hidden_dim)]
+    out, off = [], 0
+    for r, c in shapes:
+        out.append(g[off:off + r * c].reshape(r, c)); off += r * c
+    return out

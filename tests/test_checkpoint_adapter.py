@@ -64,6 +64,21 @@ def test_reference_state_dict_split_and_file_round_trip(tmp_path):
     s = ff["sigma_net.weights"]
     assert torch.equal(s[:2048].view(64, 32), sd["sigma_net.0.weight"]) and torch.equal(s[2048:2048 + 4096].view(64, 64), torch.eye(64))
     assert torch.equal(s[6144:].view(16, 64), sd["sigma_net.1.weight"])
+    # a 'best' checkpoint (nerf/utils.py:984-986 drops density_grid) with the scalars load_checkpoint restores (:1026-1030)
+    best = {k: v for k, v in sd.items() if k != "density_grid"}
+    torch.save({"model": best, "epoch": 3, "global_step": 900, "mean_count": 73211, "mean_density": 0.0625}, tmp_path / "best.pth")
+    model, extra = CK.read_checkpoint_full(str(tmp_path / "best.pth"))
+    assert "density_grid" not in model and extra == {"mean_count": 73211, "mean_density": 0.0625, "epoch": 3, "global_step": 900}
+
+    class Ren:                                                                        # the attributes load_renderer_buffers touches
+        pass
+    r = Ren()
+    r.density_grid, r.density_bitfield = torch.zeros(2, 8), torch.zeros(2, dtype=torch.uint8)
+    r.aabb_train, r.aabb_infer, r.step_counter = torch.zeros(6), torch.zeros(6), torch.zeros(16, 2, dtype=torch.int32)
+    r.mean_count, r.mean_density = 0, 0
+    CK.load_renderer_buffers(r, CK.split_state_dict(model)[1], extra)
+    assert r.mean_count == 73211 and r.mean_density == 0.0625 and torch.equal(r.density_bitfield, sd["density_bitfield"])
+    assert CK.read_checkpoint_full(str(path))[1] == {"epoch": 1}
 
 
 @pytest.mark.gpu

@@ -70,9 +70,8 @@ def test_mean_count_feedback_and_update_extra_state(scene, dev):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         for _ in range(3):
             ren.run_cuda(o, d, perturb=True)
-        gen = torch.Generator(device=dev).manual_seed(0)
         before = ren.density_bitfield.clone()
-        ren.update_extra_state(generator=gen)                               # full sweep: 2 x 128^3 density queries
+        ren.update_extra_state()                                            # full sweep: 2 x 128^3 density queries
     assert ren.iter_density == 1 and ren.local_step == 0
     assert ren.mean_count > 10000                                           # average points per step of the counter ring
     # the field represents the scene, so the re-estimated occupancy must agree with the analytic one almost everywhere

@@ -55,3 +55,20 @@ def test_oracle_camera_rays_match_the_torch_formula():
     inds = rng.integers(0, H * W, size=300)
     o2, d2 = R.camera_rays(pose, intr, H, W, inds=inds)
     assert np.array_equal(d2, d[inds]) and o2.shape == (300, 3)
+
+
+def test_psnr_meter_matches_the_oracle():
+    """R6 (nerf/utils.py:185-219)"""
+    import torch
+    from ngp.metrics import PSNRMeter
+    from oracle import callers_oracle as CO
+    rng = np.random.default_rng(0)
+    preds = [rng.uniform(size=(1, 50, 3)).astype(np.float32) for _ in range(3)]
+    truths = [np.clip(p + rng.normal(scale=0.05, size=p.shape), 0, 1).astype(np.float32) for p in preds]
+    m = PSNRMeter()
+    for p, t in zip(preds, truths):
+        m.update(torch.from_numpy(p), t)
+    assert m.N == 3 and abs(m.measure() - CO.psnr_meter(preds, truths)) < 1e-5
+    assert m.report().startswith("PSNR = ")
+    m.clear()
+    assert m.N == 0 and m.V == 0

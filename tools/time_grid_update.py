@@ -10,16 +10,15 @@ from ngp.render import NGPRenderer
 dev = torch.device("cuda:0")
 field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(W.make_model(0))
 ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
-g = torch.Generator(device=dev).manual_seed(0)
 for label, iters in (("full sweep", 3), ("partial", 6)):
     if label == "partial":
         ren.iter_density = 16
     with torch.autocast("cuda", dtype=torch.float16):
-        ren.update_extra_state(generator=g)
+        ren.update_extra_state()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            ren.update_extra_state(generator=g)
+            ren.update_extra_state()
         torch.cuda.synchronize()
     print(label, "%.2f ms per update" % ((time.perf_counter() - t0) / iters * 1e3), "mean density %.4f" % ren.mean_density,
           "occupied bits", int(sum(bin(b).count("1") for b in ren.density_bitfield.cpu().numpy().tobytes()[:4096])))
