@@ -100,7 +100,7 @@ def test_run_image_and_ray_gradients_against_oracle(linear_model, dev, upsample)
     """N2 / R3 (nerf/renderer.py:125-254, simulate.py:346): run() on 1,024 rays x 512 steps (+ 64 sample_pdf steps), staged,
     bg_color 1, perturb False -> image, depth, weights_sum and the gradient of a weighted image sum w.r.t. rays_o and rays_d (what the
     pose filter differentiates, nav/estimator_helpers.py:316).  float32 sums over 512 samples: image 2e-4 abs; gradients 2e-3 in
-    norm (cell changes of single samples between the two float32 evaluations move individual terms)."""
+    norm (5e-3 with resampling) (cell changes of single samples between the two float32 evaluations move individual terms)."""
     from oracle import callers_oracle as CO
     W, ren, orc = linear_model["W"], linear_model["ren"], linear_model["oracle"]
     o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(32, 32), 32, 32)
@@ -114,8 +114,10 @@ def test_run_image_and_ray_gradients_against_oracle(linear_model, dev, upsample)
     (ref["image"] * torch.from_numpy(G)).sum().backward()
     assert np.max(np.abs(out["image"][0].detach().cpu().numpy() - ref["image"].detach().numpy())) < 2e-4
     assert np.max(np.abs(out["depth"][0].detach().cpu().numpy() - ref["depth"].detach().numpy())) < 2e-4
-    assert rel(ro.grad[0].cpu().numpy(), co.grad.numpy()) < 2e-3
-    assert rel(rd.grad[0].cpu().numpy(), cd.grad.numpy()) < 2e-3
+    # with resampling the new depths come from a float32 CDF inversion (differences of nearly equal cumulative sums): 5e-3
+    gtol = 5e-3 if upsample else 2e-3
+    assert rel(ro.grad[0].cpu().numpy(), co.grad.numpy()) < gtol
+    assert rel(rd.grad[0].cpu().numpy(), cd.grad.numpy()) < gtol
     assert float(cd.grad.abs().max()) > 1e-3                                            # a real signal, not 0 == 0
 
 
