@@ -1,0 +1,30 @@
+// shim_common.h -- shared by the Level-2 native modules (_raymarching, _gridencoder, _shencoder, _ffmlp, _freqencoder):
+// pybind11 modules with the reference's function names and argument lists (raymarching/src/bindings.cpp:7-18 and the same
+// file in every package) that forward at::Tensor arguments, as device pointers, to the C ABI of include/ngp_hip.h.
+// Plain C++ (no .cu / .hip source, nothing hipified): every kernel lives in libngp_hip.so.
+#pragma once
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include "../../include/ngp_hip.h"
+
+namespace shim {
+
+// torch's current stream on the tensor's device (the reference launched on the legacy default stream: SURVEY 8b)
+inline void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+inline void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", ngp_last_error()); }
+
+inline void on_gpu(const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda(), name, " must be a GPU tensor (libngp_hip has no CPU path)");
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+}
+
+template <typename T> inline T* ptr(const at::Tensor& t) { return t.defined() && t.numel() ? (T*)t.data_ptr() : (T*)nullptr; }
+
+inline at::Tensor bytes_like(const at::Tensor& t, size_t n) {
+    return at::empty({(int64_t)(n ? n : 16)}, t.options().dtype(at::kByte));
+}
+
+}  // namespace shim

@@ -90,10 +90,14 @@ class FFMLP(nn.Module):
         self.output_activation = convert_activation("none")
         self.tensorcore_width = 16
 
-        assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
-        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
+        # The reference's dispatch also lists widths 16/32/128/256 and five more activations (ffmlp.cu:653-657,691-695, ffmlp.py:89-96);
+        # none of its models uses them (nerf/network_ff.py:31-49: 64 wide, ReLU).  libngp_hip implements the 64-wide ReLU networks
+        # and refuses the rest (csrc/ffmlp.hip: ffmlp_check) -- refuse here too, at construction, instead of at the first forward.
+        assert hidden_dim == 64, f"FFMLP (gfx950) supports hidden_dim 64 only (the reference lists [16, 32, 64, 128, 256]), but got {hidden_dim}"
+        assert input_dim > 0 and input_dim % 16 == 0 and input_dim <= 64, f"FFMLP (gfx950) input_dim should be 16, 32, 48 or 64, but got {input_dim}"
         assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
-        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
+        assert 2 <= num_layers <= 4, f"FFMLP (gfx950) num_layers should be 2, 3 or 4 (3 to 5 matmuls), but got {num_layers}"
+        assert self.activation == 0, f"FFMLP (gfx950) supports the ReLU hidden activation only, but got {activation!r}"
 
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
