@@ -28,21 +28,47 @@ import torch  # noqa: E402
 GATHER_BYTES_PER_SAMPLE = 512          # 16 levels x 8 corners x 2 features x 2 B
 MLP_FLOPS_PER_SAMPLE = 2 * (64 * (32 + 64 + 16) + 64 * (32 + 128 + 16))   # FFMLP shapes of nerf/network_ff.py
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+MFMA_PEAK_TFLOPS = 2500.0              # dense f16 MFMA peak (MI355X_MICROARCH.md)
+GATHER_PEAK_GBS = 8600.0               # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows, 8.6 TB/s chip-wide
+# distinct 64-byte lines one ray-sample touches: dense levels 0-4 read 4 x-pairs each (4 lines), hashed levels 5-15 read 8 entries
+# whose x-neighbours share a line 15 times out of 16 (4 + 1/4 lines): 5*4 + 11*4.25 = 66.75  (profiles/r13: 58-69 measured)
+LINES_PER_SAMPLE = 5 * 4 + 11 * 4.25
+
+
+ATOMIC_PEAK_GBS = 1300.0               # MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of added bytes, chip-wide
+SCATTER_BYTES_PER_POINT = 512          # 16 levels x 8 corners x 2 features x 2 B of half2 atomics (SURVEY 8d "training extra")
+
+
+def sources_sha16():
+    """hash of the kernel sources the built library comes from: profiles/<tag>_meta.json records it, so a PMC summary collected for
+    an older kernel cannot pass as this one's traffic"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "nerf-navigation_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ngp_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def bench_train(args, rank, world, dev, W, teacher):
     """Secondary metric: training throughput of the op-by-op path with autograd (main_nerf.py's recipe, ngp/train.py).
-    Each rank draws its own 4096-ray batches from its own views; gradients are averaged with one all-reduce per step."""
+    Each rank draws its own 4096-ray batches from its own views; gradients are averaged with one all-reduce per step.
+    Two phases are timed: `warmup_phase` = the first steps on the initial (full) occupancy grid, and the headline `steady` phase
+    after args.settle steps, when the grid has converged to the scene and a step marches ~10x fewer points."""
     import torch.distributed as dist
+    import ngp_hip
     from ngp import sharding
     from ngp.field import NGPFieldFF
     from ngp.render import NGPRenderer
     from ngp.train import NGPTrainer
     res, n_rays = 200, 4096
     intr = W.intrinsics(res, res)
+    radius, height = W.scene_orbit(args.workload)
     pool = []
     for view in sharding.pose_indices(rank, world, 8):
-        o, d = W.get_rays(W.orbit_pose(view, 8 * world), intr, res, res)
+        o, d = W.get_rays(W.orbit_pose(view, 8 * world, radius, height), intr, res, res)
         to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
         pool.append((to, td, teacher.render_fused(to, td, bg_color=1, image_width=res)["image"]))
     torch.manual_seed(0)                                                    # identical initial replicas
@@ -55,30 +81,58 @@ def bench_train(args, rank, world, dev, W, teacher):
         idx = torch.randint(0, res * res, (n_rays,), device=dev, generator=gen)
         return tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=1024)
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def points_now():
+        n = min(16, student.local_step)
+        return float(student.step_counter[:n, 0].float().mean().item()) if n else float(student.mean_count)
+
+    def timed_phase(first, count):
+        ngp_hip.TIMERS = {}
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(count):
+            loss = step(first + k)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        scatter_ms, calls = ngp_hip.timer_ms("grid_encode_backward")
+        ngp_hip.TIMERS = None
+        return elapsed, float(loss), points_now(), scatter_ms, calls
+
+    k0 = 0
     for k in range(args.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        loss = step(args.warmup + k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    n = min(16, student.local_step) or 1
-    points = float(student.step_counter[:n, 0].float().mean().item()) if student.local_step else float(student.mean_count)
+        step(k0 + k)
+    k0 += args.warmup
+    warm = timed_phase(k0, args.steps)                                      # early phase: full occupancy grid
+    k0 += args.steps
+    for k in range(args.settle):
+        step(k0 + k)
+    k0 += args.settle
+    elapsed, loss, points, scatter_ms, calls = timed_phase(k0, args.steps)  # steady state
     rays_all, t_max = sharding.reduce_throughput(n_rays * args.steps, elapsed, dev)
     if rank == 0:
+        def roof(pts, ms):
+            if not ms:
+                return None
+            a = SCATTER_BYTES_PER_POINT * pts / (ms * 1e-3) / 1e9
+            return {"bound": "atomic", "kernel": "k_grid_backward<half,3,2>", "achieved": a, "peak": ATOMIC_PEAK_GBS, "unit": "GB/s",
+                    "frac": a / ATOMIC_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                    "algorithmic_bytes_per_point": SCATTER_BYTES_PER_POINT, "points_per_launch": pts}
         print(json.dumps({
             "metric": "training rays/sec (4096-ray steps, FFMLP field under autocast, Adam, grid refresh every 16 steps)",
             "value": rays_all / t_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "S-ring training (teacher-rendered 200x200 views), op-by-op HIP path with autograd",
-                       "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": float(loss)}}))
+            "config": {"workload": f"S-{args.workload} training (teacher-rendered 200x200 views), op-by-op HIP path with autograd, steady state after "
+                                   f"{args.warmup + args.steps + args.settle} steps",
+                       "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": loss},
+            "roofline": roof(points, scatter_ms),
+            "warmup_phase": {"ms_per_step": 1e3 * warm[0] / args.steps, "points_per_step": warm[2], "loss": warm[1],
+                             "roofline": roof(warm[2], warm[3])}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -94,6 +148,12 @@ def main():
     ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "per_op", "per_op_fused_field"],
                     help="fused = headline (rays resident); fused_camera = rays generated inside the frame kernel from the pose; "
                          "fused_torch_rays = torch get_rays per frame + fused; per_op = the reference-shaped op-by-op loop")
+    ap.add_argument("--workload", default="ring", choices=["ring", "church"],
+                    help="ring = S-ring, the BASELINE config-2 stand-in (headline); church = the larger shell scene of config 5")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank renders its own frames (headline); strong = every frame is cut into row bands, one per rank")
+    ap.add_argument("--gather", action="store_true", help="strong scaling: all-gather the row bands into the full image on every rank, inside the timed region")
+    ap.add_argument("--settle", type=int, default=160, help="train mode: untimed steps between the warm-up phase and the steady-state phase")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render = the headline metric; train = secondary: training steps (configs 3 / 5), 4096 rays per step per GPU")
     args = ap.parse_args()
@@ -121,8 +181,8 @@ def main():
     from ngp.field import NGPFieldFF
     from ngp.render import NGPRenderer
 
-    model = W.make_model(0)
-    grid = W.density_grid()
+    model = W.make_model(0, scene=args.workload)
+    grid = W.density_grid(scene=args.workload)
     field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(model)
     ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
     ren.load_density_grid(grid)
@@ -133,14 +193,25 @@ def main():
     H = Wd = args.res
     intr = W.intrinsics(H, Wd)
     n_poses = 8
-    # every rank walks the same orbit, phase-shifted by its rank, so ranks never render the same view at the same step
+    radius, height = W.scene_orbit(args.workload)
     from ngp import sharding
+    strong = args.scaling == "strong" and world > 1
     rays, poses = [], []
-    for view in sharding.pose_indices(rank, world, n_poses):
-        poses.append(W.orbit_pose(view, n_poses * world).astype(np.float32))
-        o, d = W.get_rays(poses[-1], intr, H, Wd)
-        rays.append((torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]))
-    N = H * Wd
+    if strong:
+        # strong scaling: ONE stream of frames; rank r renders rows [lo, hi) of every frame (contiguous bands keep ray coherence)
+        assert args.path == "fused", "--scaling strong is implemented for the fused path"
+        lo, hi = sharding.row_band(rank, world, H)
+        for view in range(n_poses):
+            poses.append(W.orbit_pose(view, n_poses, radius, height).astype(np.float32))
+            o, d = W.get_rays(poses[-1], intr, H, Wd)
+            rays.append((torch.from_numpy(o[lo * Wd:hi * Wd]).to(dev)[None], torch.from_numpy(d[lo * Wd:hi * Wd]).to(dev)[None]))
+    else:
+        # weak scaling: every rank walks the same orbit, phase-shifted by its rank, so ranks never render the same view at the same step
+        for view in sharding.pose_indices(rank, world, n_poses):
+            poses.append(W.orbit_pose(view, n_poses * world, radius, height).astype(np.float32))
+            o, d = W.get_rays(poses[-1], intr, H, Wd)
+            rays.append((torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]))
+    N = rays[0][0].shape[1]
     fused = args.path.startswith("fused")
     poses_dev = [torch.from_numpy(p)[None].to(dev) for p in poses]
 
@@ -153,7 +224,10 @@ def main():
             r = get_rays(poses_dev[k % n_poses], intr, H, Wd)
             return ren.render_fused(r["rays_o"], r["rays_d"], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
         if args.path == "fused":
-            return ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
+            out = ren.render_fused(o, d, dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
+            if strong and args.gather:
+                out["full_image"] = sharding.gather_rows(out["image"][0].view(-1, Wd, 3))
+            return out
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024,
                                 fused_field=(args.path == "per_op_fused_field"))
@@ -211,14 +285,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
         "config": {
-            "workload": f"S-ring {H}x{Wd} novel-view render (synthetic Stonehenge stand-in, bound 2, dt_gamma 0, max_steps 1024), "
+            "workload": f"S-{args.workload} {H}x{Wd} novel-view render (synthetic Stonehenge stand-in, bound 2, dt_gamma 0, max_steps 1024), "
                         f"hashgrid(16x2, 2^19, f16) + FFMLP(32-64-64-16 | 32-64-64-64-16) + occupancy march, path={args.path}",
             "rays_per_frame": N,
+            "row_band_per_gpu": f"{hi - lo} of {H} rows" if strong else "all rows",
             "frames_per_gpu": args.steps,
             "samples_per_ray": samples_per_launch / N,
             "poses": n_poses,
@@ -236,6 +311,15 @@ def main():
             "avg_launch_ms": 1e3 * avg_kernel_s,
             "algorithmic_bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
             "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,
+            "mfma_frac": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12 / MFMA_PEAK_TFLOPS,
+            # second ceiling: the table is Infinity-Cache / L2 resident and read by scattered gathers, so the HBM figure above
+            # is not what bounds the kernel.  The guide's random-row gather from a 38 MB table reaches 8.6 TB/s with 1,152-B rows;
+            # here a "row" is one 4-byte (hashed levels) or 8-byte (dense x-pair) entry of a 64-byte line, i.e. the useful fraction
+            # of every line fetched is 1/16..1/8: the same line rate moves at most 8.6 TB/s x (512 B useful / 4,864 B of lines per sample).
+            "gather_ceiling": {"lines_per_sample": LINES_PER_SAMPLE, "line_bytes": 64,
+                               "line_rate_achieved_GBs": LINES_PER_SAMPLE * 64 * samples_per_launch / avg_kernel_s / 1e9,
+                               "line_rate_peak_GBs": GATHER_PEAK_GBS,
+                               "frac": LINES_PER_SAMPLE * 64 * samples_per_launch / avg_kernel_s / 1e9 / GATHER_PEAK_GBS},
         },
     }
 
@@ -248,18 +332,25 @@ def main():
         import glob
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))[-1]
         c = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(pmc))}
-        if args.path == "fused" and args.res == 800:
-            result["roofline"]["traffic"] = (c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
-            result["roofline"]["traffic_unit"] = "bytes per launch (L2-miss / fabric side; table is Infinity-Cache resident)"
-            result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
-    except (IndexError, KeyError, OSError):
+        meta = pmc.replace("_pmc.csv", "_meta.json")
+        recorded = json.load(open(meta)).get("sources_sha16") if os.path.exists(meta) else None
+        if args.path == "fused" and args.res == 800 and args.workload == "ring" and not strong:
+            if recorded == sources_sha16():
+                result["roofline"]["traffic"] = (c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
+                result["roofline"]["traffic_unit"] = "bytes per launch (L2-miss / fabric side; table is Infinity-Cache resident)"
+                result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
+            else:
+                # the committed counters were collected for other kernel sources than the ones built here: not this kernel's traffic
+                result["roofline"]["traffic_stale"] = {"profile": os.path.relpath(pmc, ROOT), "profile_sources": recorded,
+                                                       "built_sources": sources_sha16()}
+    except (IndexError, KeyError, OSError, ValueError):
         pass
 
     if not args.no_cpu and world == 1:
         from oracle import ngp_oracle as O, render_oracle as R
         O.build()
         r = args.cpu_res
-        o, d = W.get_rays(W.orbit_pose(0, n_poses), W.intrinsics(r, r), r, r)
+        o, d = W.get_rays(W.orbit_pose(0, n_poses, radius, height), W.intrinsics(r, r), r, r)
         bitfield = ren.density_bitfield.cpu().numpy()
         t1 = time.perf_counter()
         ref = R.run_cuda(lambda x, dd: R.field_forward(model, x, dd, 1.0), o, d, bitfield, W.BOUND, 2)
@@ -273,8 +364,9 @@ def main():
             "unit": "ray-samples/s",
             "cores": len(os.sched_getaffinity(0)),
             "kind": "port",
-            "sample": f"one {r}x{r} frame of the same scene and model through oracle run_cuda "
-                      f"({ref['samples']} ray-samples, {cpu_s:.1f} s, OpenMP over the cores this process may use)",
+            "sample": f"one {r}x{r} frame of the same scene and model through the oracle's run_cuda, an UNOPTIMISED checker "
+                      f"(bit-faithful restatement in chunked numpy + C, the reference has no CPU path): "
+                      f"{ref['samples']} ray-samples in {cpu_s:.1f} s, OpenMP over the cores this process may use; a stated baseline, not a target",
         }
     print(json.dumps(result))
     if world > 1:

@@ -87,11 +87,12 @@ class _grid_encode(Function):
             grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
 
         if need_table or not ctx.recompute:
-            _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
-                                                           _hip.ptr(grad_embeddings) if need_table else None, B, D, C, L, float(S), H,
-                                                           int(calc_grad_inputs and not ctx.recompute),
-                                                           _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
-                                                           _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")
+            with _hip.timed("grid_encode_backward"):
+                _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
+                                                               _hip.ptr(grad_embeddings) if need_table else None, B, D, C, L, float(S), H,
+                                                               int(calc_grad_inputs and not ctx.recompute),
+                                                               _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
+                                                               _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")
         if ctx.recompute:
             _hip.check(_hip.lib().ngp_grid_encode_backward_inputs(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
                                                                   B, D, C, L, float(S), H, _hip.ptr(grad_inputs), gridtype,

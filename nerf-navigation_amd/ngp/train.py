@@ -64,7 +64,9 @@ class NGPTrainer:
         self.update_extra_interval = update_extra_interval
         self.opt = torch.optim.Adam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
-        self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+        # the device type comes from the model so that the 2-rank CPU rehearsal (tests/test_distributed_cpu.py, gloo) runs the very same step
+        self.device_type = next(renderer.parameters()).device.type
+        self.scaler = torch.amp.GradScaler(self.device_type, enabled=fp16)
         self.exchange = GradExchange(list(renderer.field.parameters()))
         self.global_step = 0
         # the same pcg32 seed on every rank keeps the density grids of the replicas identical
@@ -74,10 +76,10 @@ class NGPTrainer:
         """One optimisation step on a [1, N, 3] ray batch; returns the (unscaled) loss as a tensor."""
         ren = self.ren.train()
         if self.global_step % self.update_extra_interval == 0:
-            with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 ren.update_extra_state()
         self.opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
             out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)
             loss = torch.nn.functional.mse_loss(out["image"], target)
         self.scaler.scale(loss).backward()

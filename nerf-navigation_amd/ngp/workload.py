@@ -18,8 +18,33 @@ SIGMA_IN = 60.0
 P1, P2 = np.uint32(2654435761), np.uint32(805459861)
 
 
-def scene_boxes():
-    """[(lo[3], hi[3])] in world units."""
+def church_boxes():
+    """Scene "shell" of BASELINE config 5 ("the same generator with a larger shell scene, bound 2"): a hollow
+    church -- nave walls, a stepped roof, a tower, a floor and two rows of interior columns -- filling most of the inner cascade
+    and reaching into the outer one, so that rays cross several thin occupied shells and much more of the grid is occupied than
+    in the ring scene (more samples per ray, more table rows touched)."""
+    t = 0.07                                                   # wall thickness
+    L, Wd, Hh = 1.5, 0.8, 0.9                                  # half length (x), half width (y), wall height (z)
+    boxes = [((-L, -Wd, -0.05), (L, Wd, 0.0)),                 # floor
+             ((-L, -Wd, 0.0), (L, -Wd + t, Hh)), ((-L, Wd - t, 0.0), (L, Wd, Hh)),          # long walls
+             ((-L, -Wd, 0.0), (-L + t, Wd, Hh)), ((L - t, -Wd, 0.0), (L, Wd, Hh))]          # end walls
+    for k in range(6):                                         # stepped gable roof: slabs narrowing towards the ridge
+        w = Wd * (1 - k / 6)
+        boxes.append(((-L, -w, Hh + 0.09 * k), (L, w, Hh + 0.09 * k + t)))
+    boxes.append(((L - 0.1, -0.3, 0.0), (L + 0.5, 0.3, 1.85)))                               # tower (solid shell approximated by a block wall set)
+    boxes.append(((L + 0.05, -0.2, 1.85), (L + 0.35, 0.2, 1.97)))
+    for k in range(7):                                         # two rows of columns
+        x = -1.2 + 0.4 * k
+        for y in (-0.4, 0.4):
+            boxes.append(((x - 0.04, y - 0.04, 0.0), (x + 0.04, y + 0.04, Hh)))
+    return [(np.array(lo, np.float64), np.array(hi, np.float64)) for lo, hi in boxes]
+
+
+def scene_boxes(scene="ring"):
+    """[(lo[3], hi[3])] in world units.  scene: "ring" (BASELINE config 2-4) or "church" (config 5)."""
+    if scene == "church":
+        return church_boxes()
+    assert scene == "ring", scene
     boxes = []
     for k in range(12):
         a = 2 * math.pi * k / 12
@@ -61,9 +86,9 @@ def cascade_count(bound):
     return 1 + math.ceil(math.log2(bound))                   # nerf/renderer.py:73
 
 
-def density_grid(bound=BOUND, H=GRID, boxes=None):
+def density_grid(bound=BOUND, H=GRID, boxes=None, scene="ring"):
     """Analytic density grid [cascade, H^3] float32 in Morton order: SIGMA_IN in every cell a box touches."""
-    boxes = boxes or scene_boxes()
+    boxes = boxes or scene_boxes(scene)
     cas = cascade_count(bound)
     grid = np.zeros((cas, H ** 3), np.float32)
     for c in range(cas):
@@ -106,7 +131,7 @@ OCC_LEVEL = 6          # hashed level that carries the occupancy feature (cell 4
 ONE_LEVEL = 0          # dense level whose second feature is the constant 1
 
 
-def make_model(seed=0, bound=BOUND):
+def make_model(seed=0, bound=BOUND, scene="ring"):
     """Returns dict(embeddings f32 [sO,2], offsets, per_level_scale, sigma_weights f32 [7168], color_weights f32 [11264])
     in the layouts of GridEncoder.embeddings / FFMLP.weights (gridencoder/grid.py:129, ffmlp/ffmlp.py:121-122)."""
     rng = np.random.default_rng(seed)
@@ -124,7 +149,7 @@ def make_model(seed=0, bound=BOUND):
     emb[offsets[OCC_LEVEL]:offsets[OCC_LEVEL + 1], 0] = 0.0
     ii = np.arange(res + 1, dtype=np.float64)
     world = ((ii - 0.5) / float(scale)) * 2 * bound - bound          # vertex i sits at x01 = (i - 0.5) / scale
-    for lo, hi in scene_boxes():
+    for lo, hi in scene_boxes(scene):
         sel = [np.flatnonzero((world >= lo[d]) & (world <= hi[d])).astype(np.uint32) for d in range(3)]
         if min(len(s) for s in sel) == 0:
             continue
@@ -150,6 +175,11 @@ def intrinsics(H, W, fovx=0.6911):
     """(fx, fy, cx, cy) of a square-pixel pinhole; fovx is nerf_synthetic's camera_angle_x."""
     f = 0.5 * W / math.tan(0.5 * fovx)
     return np.array([f, f, W / 2, H / 2], np.float32)
+
+
+def scene_orbit(scene="ring"):
+    """(radius, height) of the test-pose orbit: the ring scene is viewed from 1.6; the church is larger, 2.3 keeps the camera outside it"""
+    return (2.3, 0.9) if scene == "church" else (1.6, 0.6)
 
 
 def orbit_pose(k, n=8, radius=1.6, height=0.6):

@@ -107,6 +107,38 @@ def lib():
     return _lib
 
 
+# Optional live timing of individual native calls (bench.py's roofline of a kernel inside a multi-kernel step): set
+# `ngp_hip.TIMERS = {}` and every `with timed(name):` block records a HIP event pair on the current stream; None = no overhead.
+TIMERS = None
+
+
+class timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            self.ev[1].record()
+            TIMERS.setdefault(self.name, []).append(self.ev)
+        return False
+
+
+def timer_ms(name):
+    """mean / count of the recorded intervals of `name` (synchronises)"""
+    ev = (TIMERS or {}).get(name, [])
+    if not ev:
+        return None, 0
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    return sum(ms) / len(ms), len(ms)
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().ngp_last_error().decode(errors="replace")

@@ -98,3 +98,96 @@ def test_two_rank_gradient_exchange():
     for rank, tmean, w1g, w2g, nbig, nsmall in res:
         assert tmean == 1.5 and nbig == 1 and nsmall == 2            # (1 + 2) / 2
         assert torch.equal(w1g, base * 1.5) and torch.equal(w2g, torch.zeros(16))
+
+
+class _MockField(torch.nn.Module):
+    """stands in for NGPFieldFF on the CPU: a big "table" (reduced in place) and small "weights" (bucketed)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)                                            # identical replicas
+        self.table = torch.nn.Parameter(torch.randn(4096, 2) * 0.1)
+        self.w = torch.nn.Parameter(torch.randn(3, 2) * 0.5)
+
+    def get_params(self, lr):
+        return [{"params": [self.table], "lr": lr}, {"params": [self.w], "lr": lr}]
+
+
+class _MockRenderer(torch.nn.Module):
+    """the surface NGPTrainer.step touches (ngp/render.py: run_cuda, update_extra_state, grid_seed, field) without a GPU: the image
+    is a differentiable function of the parameters and the rays; the grid refresh is a deterministic function of (grid_seed,
+    iter_density, parameters), like the native one"""
+
+    def __init__(self, poison=None):
+        super().__init__()
+        self.field = _MockField()
+        self.register_buffer("density_bitfield", torch.zeros(64, dtype=torch.uint8))
+        self.grid_seed, self.iter_density, self.poison, self.calls = 0, 0, poison, 0
+
+    def run_cuda(self, rays_o, rays_d, bg_color=1, perturb=False, force_all_rays=False, **kw):
+        idx = (rays_o[0, :, 0].abs() * 1000).long() % 4096
+        feat = self.field.table[idx] * rays_d[0, :, :2]
+        image = torch.sigmoid(feat @ self.field.w.t())[None]
+        if self.poison is not None and self.calls == self.poison:       # an overflow on THIS rank only
+            image = image * float("inf")
+        self.calls += 1
+        return {"image": image}
+
+    def update_extra_state(self):
+        g = torch.Generator().manual_seed(self.grid_seed * 1000 + self.iter_density)
+        noise = torch.rand(64, generator=g)
+        self.density_bitfield = ((self.field.table.detach()[:64, 0] + noise) > 0.5).to(torch.uint8)
+        self.iter_density += 1
+
+
+def _trainer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import importlib
+    importlib.import_module("nerf-navigation_amd")
+    from ngp.train import NGPTrainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ren = _MockRenderer(poison=7 if rank == 1 else None)
+        tr = NGPTrainer(ren, lr=1e-2, iters=100, fp16=True, update_extra_interval=4, seed=5)
+        tr.exchange.big = [ren.field.table]                             # 8 K elements: force the in-place route for the table
+        tr.exchange.small = [ren.field.w]
+        g = torch.Generator().manual_seed(100 + rank)                   # every rank draws its OWN ray batch
+        scales, skipped = [], []
+        for step in range(20):
+            o = torch.rand(1, 256, 3, generator=g)
+            d = torch.randn(1, 256, 3, generator=g)
+            target = torch.rand(1, 256, 3, generator=g)
+            before = ren.field.w.detach().clone()
+            loss = tr.step(o, d, target)
+            skipped.append(bool(torch.equal(before, ren.field.w.detach())))
+            scales.append(float(tr.scaler.get_scale()))
+        # plain bytes through the queue: tensors would travel as shared-memory handles that die with this process
+        out.put((rank, ren.field.table.detach().numpy().tobytes(), ren.field.w.detach().numpy().tobytes(),
+                 ren.density_bitfield.numpy().tobytes(), scales, skipped, ren.iter_density, float(loss) == float(loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trainer_replicas_stay_identical():
+    """config 5, rehearsed on CPU: NGPTrainer.step x 20 on two ranks with different ray batches and ONE all-reduce per step.  After
+    every step the replicas hold identical parameters; an overflow on rank 1 only (step 7) makes BOTH ranks skip that step and halve
+    the loss scale (the inf travels with the summed gradients); the seeded grid refresh leaves identical bitfields."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, t0, w0, b0, s0, k0, it0, _), (_, t1, w1, b1, s1, k1, it1, _) = res
+    assert t0 == t1 and w0 == w1 and b0 == b1 and it0 == it1 == 5
+    assert s0 == s1 and k0 == k1
+    assert k0[7] and not any(k0[:7]) and not any(k0[8:])                 # the poisoned step is skipped on both ranks, and only that one
+    assert s0[7] == 0.5 * s0[6]
+    fresh = _MockField()
+    assert fresh.w.detach().numpy().tobytes() != w0                                # and training did move the parameters

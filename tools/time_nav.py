@@ -1,61 +1,128 @@
 """Time BASELINE config 4 (nav loop pieces, fp32, no autocast) on cuda:0:
-   (ii) density + backward on [20,500,3] body points (planner);  (iii) run() render + backward, 1024 rays x 512 steps (filter)."""
-import importlib, os, sys, time
-import numpy as np
+   (ii) density + backward on [20,500,3] body points (planner, nav/quad_plot.py:224-250);
+   (iii) run() render + backward, 1024 rays x 512 steps (pose filter, nav/estimator_helpers.py:293-327).
+Prints one line per variant and a final JSON line (`ms_per_step` = the frozen-model filter iteration).
+   python tools/time_nav.py [--steps 20] [--warmup 1] [--torch-profile]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
 import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 importlib.import_module("nerf-navigation_amd")
-from ngp import workload as W
-from ngp.field import NGPField
-from ngp.render import NGPRenderer
+from ngp import nav  # noqa: E402
+from ngp import workload as W  # noqa: E402
+from ngp.field import NGPField  # noqa: E402
+from ngp.render import NGPRenderer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--torch-profile", action="store_true", help="print torch.profiler's kernel table for the filter iteration")
+ap.add_argument("--only", default="", help="comma list of: planner, filter, planner_frozen, filter_frozen, planner_graphed, planner_native, filter_native")
+args = ap.parse_args()
+only = set(filter(None, args.only.split(",")))
+
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 field = NGPField(bound=W.BOUND).to(dev)
 with torch.no_grad():
     field.encoder.embeddings.uniform_(-0.5, 0.5)
 ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=False).to(dev).eval()
-rot = torch.tensor([[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]], device=dev)
+rot = torch.tensor(nav.ROT, device=dev)
+
 
 def timeit(fn, n):
-    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(max(args.warmup, 1)):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(n):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
+
 pts = (torch.rand(20, 500, 3, device=dev) * 2 - 1)
+o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(32, 32), 32, 32)
+o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+res = {}
+
+
 def planner():
     p = pts.clone().requires_grad_(True)
     ren.density(p.reshape(-1, 3) @ rot)["sigma"].sum().backward()
-print("(ii) density+backward on 10,000 points: %.3f ms" % timeit(planner, 50))
 
-o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(32, 32), 32, 32)
-o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+
 def filt():
     ro, rd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
     out = ren.render(ro, rd, staged=True, bg_color=1.0, perturb=False, num_steps=512, upsample_steps=0, max_ray_batch=4096)
     out["image"].sum().backward()
-print("(iii) run() 1024 rays x 512 steps + backward: %.3f ms" % timeit(filt, 20))
 
-from ngp import nav
+
+def want(name):
+    return not only or name in only
+
+
+if want("planner"):
+    res["planner"] = timeit(planner, 2 * args.steps)
+    print("(ii) density+backward on 10,000 points, reference structure (trainable model): %.3f ms" % res["planner"])
+if want("filter"):
+    res["filter"] = timeit(filt, args.steps)
+    print("(iii) run() 1024 rays x 512 steps + backward, reference structure: %.3f ms" % res["filter"])
+
 q = nav.NavQueries(ren, W.intrinsics(32, 32), 32, 32)
+
+
 def planner_frozen():
     p = pts.clone().requires_grad_(True)
     q.density_fn(p).sum().backward()
+
+
 def filt_frozen():
     ro, rd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
     q.render_fn(ro, rd)["image"].sum().backward()
-print("frozen model: (ii) %.3f ms   (iii) %.3f ms" % (timeit(planner_frozen, 50), timeit(filt_frozen, 20)))
-filt = filt_frozen
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
-    for _ in range(3):
-        filt()
-    torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
-dens = nav.GraphedDensity(q, n_points=pts.numel() // 3)
-def planner_graphed():
-    p = pts.clone().requires_grad_(True)
-    dens(p).sum().backward()
-print("frozen model, one graph replay per planner query: (ii) %.3f ms" % timeit(planner_graphed, 200))
+
+
+if want("planner_frozen"):
+    res["planner_frozen"] = timeit(planner_frozen, 2 * args.steps)
+if want("filter_frozen"):
+    res["filter_frozen"] = timeit(filt_frozen, args.steps)
+    print("frozen model: (ii) %.3f ms   (iii) %.3f ms" % (res.get("planner_frozen", float("nan")), res["filter_frozen"]))
+if args.torch_profile:
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(3):
+            filt_frozen()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
+if want("planner_graphed"):
+    dens = nav.GraphedDensity(q, n_points=pts.numel() // 3)
+
+    def planner_graphed():
+        p = pts.clone().requires_grad_(True)
+        dens(p).sum().backward()
+    res["planner_graphed"] = timeit(planner_graphed, 10 * args.steps)
+    print("frozen model, one graph replay per planner query: (ii) %.3f ms" % res["planner_graphed"])
+if hasattr(nav, "NativeNavQueries"):
+    nq = nav.NativeNavQueries(ren, W.intrinsics(32, 32), 32, 32)
+
+    def planner_native():
+        p = pts.clone().requires_grad_(True)
+        nq.density_fn(p).sum().backward()
+
+    def filt_native():
+        ro, rd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        nq.render_fn(ro, rd)["image"].sum().backward()
+    if want("planner_native"):
+        res["planner_native"] = timeit(planner_native, 10 * args.steps)
+    if want("filter_native"):
+        res["filter_native"] = timeit(filt_native, args.steps)
+    print("native fused fp32 queries: (ii) %.3f ms   (iii) %.3f ms" % (res.get("planner_native", float("nan")), res.get("filter_native", float("nan"))))
+main = res.get("filter_native", res.get("filter_frozen", float("nan")))
+print(json.dumps({"metric": "nav-loop query times (BASELINE config 4), ms", "ms_per_step": main, "steps": args.steps, **{k: round(v, 4) for k, v in res.items()}}))
