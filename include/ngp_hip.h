@@ -104,6 +104,13 @@ int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
                    uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                    float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream);
 
+/* The same with the zero-initialisation of the wrapper (raymarching/raymarching.py:327-329) done by the kernel: xyzs, dirs [M,3],
+ * deltas [M,2] need NOT be pre-zeroed; every row is written (M >= n_alive * n_step: the wrapper's padded row count). */
+int ngp_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                        const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                        uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                        float* xyzs, float* dirs, float* deltas, uint32_t M, uint32_t perturb, void* stream);
+
 /* raymarching.h:18 composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
  * mutates rays_alive (-1 = dead), rays_t, weights_sum, depth, image in place. */
 int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,

@@ -11,7 +11,7 @@ void ffmlp_forward(const at::Tensor inputs, const at::Tensor weights, const uint
                    const uint32_t hidden_dim, const uint32_t num_layers, const uint32_t activation_, const uint32_t output_activation_,
                    at::Tensor forward_buffer, at::Tensor outputs) {
     check_half(inputs, "inputs"); check_half(weights, "weights"); check_half(forward_buffer, "forward_buffer"); check_half(outputs, "outputs");
-    c10::hip::HIPGuard g(inputs.device());
+    device_guard g(inputs.device());
     ok(ngp_ffmlp_forward(inputs.data_ptr(), weights.data_ptr(), B, input_dim, output_dim, hidden_dim, num_layers, activation_, output_activation_,
                          forward_buffer.data_ptr(), outputs.data_ptr(), stream_of(inputs)), "ffmlp_forward");
 }
@@ -20,7 +20,7 @@ void ffmlp_inference(const at::Tensor inputs, const at::Tensor weights, const ui
                      const uint32_t hidden_dim, const uint32_t num_layers, const uint32_t activation_, const uint32_t output_activation_,
                      at::Tensor inference_buffer, at::Tensor outputs) {
     check_half(inputs, "inputs"); check_half(weights, "weights"); check_half(outputs, "outputs");
-    c10::hip::HIPGuard g(inputs.device());
+    device_guard g(inputs.device());
     ok(ngp_ffmlp_inference(inputs.data_ptr(), weights.data_ptr(), B, input_dim, output_dim, hidden_dim, num_layers, activation_, output_activation_,
                            inference_buffer.defined() ? inference_buffer.data_ptr() : nullptr, outputs.data_ptr(), stream_of(inputs)), "ffmlp_inference");
 }
@@ -31,7 +31,7 @@ void ffmlp_backward(const at::Tensor grad, const at::Tensor inputs, const at::Te
                     at::Tensor grad_weights) {
     check_half(grad, "grad"); check_half(inputs, "inputs"); check_half(weights, "weights"); check_half(forward_buffer, "forward_buffer");
     check_half(backward_buffer, "backward_buffer"); check_half(grad_weights, "grad_weights");
-    c10::hip::HIPGuard g(inputs.device());
+    device_guard g(inputs.device());
     at::Tensor ws = bytes_like(inputs, ngp_ffmlp_backward_workspace(input_dim, output_dim, hidden_dim, num_layers));   // the reference's GPUMemory scratch
     ok(ngp_ffmlp_backward(grad.data_ptr(), inputs.data_ptr(), weights.data_ptr(), forward_buffer.data_ptr(), B, input_dim, output_dim, hidden_dim, num_layers,
                           activation, output_activation, calc_grad_inputs ? 1 : 0, backward_buffer.data_ptr(),

@@ -14,7 +14,7 @@ void grid_encode_forward(const at::Tensor inputs, const at::Tensor embeddings, c
     TORCH_CHECK(inputs.scalar_type() == at::kFloat, "inputs must be float32");
     TORCH_CHECK(offsets.scalar_type() == at::kInt, "offsets must be int32");
     TORCH_CHECK(outputs.scalar_type() == embeddings.scalar_type(), "outputs must have the table's dtype");
-    c10::hip::HIPGuard g(inputs.device());
+    device_guard g(inputs.device());
     ok(ngp_grid_encode_forward(ptr<float>(inputs), embeddings.data_ptr(), ptr<int32_t>(offsets), outputs.data_ptr(), B, D, C, L, S, H,
                                calc_grad_inputs ? 1 : 0, calc_grad_inputs ? dy_dx.data_ptr() : nullptr, gridtype, align_corners ? 1 : 0,
                                table_dtype(embeddings), stream_of(inputs)), "grid_encode_forward");
@@ -27,7 +27,7 @@ void grid_encode_backward(const at::Tensor grad, const at::Tensor inputs, const 
     on_gpu(grad, "grad"); on_gpu(inputs, "inputs"); on_gpu(embeddings, "embeddings"); on_gpu(offsets, "offsets"); on_gpu(grad_embeddings, "grad_embeddings");
     TORCH_CHECK(grad.scalar_type() == embeddings.scalar_type() && grad_embeddings.scalar_type() == embeddings.scalar_type(),
                 "grad and grad_embeddings must have the table's dtype");
-    c10::hip::HIPGuard g(inputs.device());
+    device_guard g(inputs.device());
     ok(ngp_grid_encode_backward(grad.data_ptr(), ptr<float>(inputs), embeddings.data_ptr(), ptr<int32_t>(offsets), grad_embeddings.data_ptr(), B, D, C, L,
                                 S, H, calc_grad_inputs ? 1 : 0, calc_grad_inputs ? dy_dx.data_ptr() : nullptr,
                                 calc_grad_inputs ? grad_inputs.data_ptr() : nullptr, gridtype, align_corners ? 1 : 0, table_dtype(embeddings),

@@ -5,32 +5,32 @@ using namespace shim;
 void near_far_from_aabb(const at::Tensor rays_o, const at::Tensor rays_d, const at::Tensor aabb, const uint32_t N, const float min_near,
                         at::Tensor nears, at::Tensor fars) {
     on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(aabb, "aabb"); on_gpu(nears, "nears"); on_gpu(fars, "fars");
-    c10::hip::HIPGuard g(rays_o.device());
+    device_guard g(rays_o.device());
     ok(ngp_near_far_from_aabb(ptr<float>(rays_o), ptr<float>(rays_d), ptr<float>(aabb), N, min_near, ptr<float>(nears), ptr<float>(fars),
                               stream_of(rays_o)), "near_far_from_aabb");
 }
 
 void sph_from_ray(const at::Tensor rays_o, const at::Tensor rays_d, const float radius, const uint32_t N, at::Tensor coords) {
     on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(coords, "coords");
-    c10::hip::HIPGuard g(rays_o.device());
+    device_guard g(rays_o.device());
     ok(ngp_sph_from_ray(ptr<float>(rays_o), ptr<float>(rays_d), radius, N, ptr<float>(coords), stream_of(rays_o)), "sph_from_ray");
 }
 
 void morton3D(const at::Tensor coords, const uint32_t N, at::Tensor indices) {
     on_gpu(coords, "coords"); on_gpu(indices, "indices");
-    c10::hip::HIPGuard g(coords.device());
+    device_guard g(coords.device());
     ok(ngp_morton3D(ptr<int32_t>(coords), N, ptr<int32_t>(indices), stream_of(coords)), "morton3D");
 }
 
 void morton3D_invert(const at::Tensor indices, const uint32_t N, at::Tensor coords) {
     on_gpu(indices, "indices"); on_gpu(coords, "coords");
-    c10::hip::HIPGuard g(indices.device());
+    device_guard g(indices.device());
     ok(ngp_morton3D_invert(ptr<int32_t>(indices), N, ptr<int32_t>(coords), stream_of(indices)), "morton3D_invert");
 }
 
 void packbits(const at::Tensor grid, const uint32_t N, const float density_thresh, at::Tensor bitfield) {
     on_gpu(grid, "grid"); on_gpu(bitfield, "bitfield");
-    c10::hip::HIPGuard g(grid.device());
+    device_guard g(grid.device());
     ok(ngp_packbits(ptr<float>(grid), N, density_thresh, ptr<uint8_t>(bitfield), stream_of(grid)), "packbits");
 }
 
@@ -39,7 +39,7 @@ void march_rays_train(const at::Tensor rays_o, const at::Tensor rays_d, const at
                       const at::Tensor fars, at::Tensor xyzs, at::Tensor dirs, at::Tensor deltas, at::Tensor rays, at::Tensor counter,
                       const uint32_t perturb) {
     on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(grid, "grid"); on_gpu(xyzs, "xyzs"); on_gpu(rays, "rays"); on_gpu(counter, "counter");
-    c10::hip::HIPGuard g(rays_o.device());
+    device_guard g(rays_o.device());
     at::Tensor ws = bytes_like(rays_o, ngp_march_rays_train_workspace_full(N, max_steps));       // the only hidden allocation, as the wrapper's
     ok(ngp_march_rays_train(ptr<float>(rays_o), ptr<float>(rays_d), ptr<uint8_t>(grid), bound, dt_gamma, max_steps, N, C, H, M, ptr<float>(nears),
                             ptr<float>(fars), ptr<float>(xyzs), ptr<float>(dirs), ptr<float>(deltas), ptr<int32_t>(rays), ptr<int32_t>(counter),
@@ -49,7 +49,7 @@ void march_rays_train(const at::Tensor rays_o, const at::Tensor rays_d, const at
 void composite_rays_train_forward(const at::Tensor sigmas, const at::Tensor rgbs, const at::Tensor deltas, const at::Tensor rays, const uint32_t M,
                                   const uint32_t N, at::Tensor weights_sum, at::Tensor depth, at::Tensor image) {
     on_gpu(sigmas, "sigmas"); on_gpu(rgbs, "rgbs"); on_gpu(deltas, "deltas"); on_gpu(rays, "rays");
-    c10::hip::HIPGuard g(sigmas.device());
+    device_guard g(sigmas.device());
     ok(ngp_composite_rays_train_forward(ptr<float>(sigmas), ptr<float>(rgbs), ptr<float>(deltas), ptr<int32_t>(rays), M, N, ptr<float>(weights_sum),
                                         ptr<float>(depth), ptr<float>(image), stream_of(sigmas)), "composite_rays_train_forward");
 }
@@ -58,7 +58,7 @@ void composite_rays_train_backward(const at::Tensor grad_weights_sum, const at::
                                    const at::Tensor deltas, const at::Tensor rays, const at::Tensor weights_sum, const at::Tensor image,
                                    const uint32_t M, const uint32_t N, at::Tensor grad_sigmas, at::Tensor grad_rgbs) {
     on_gpu(grad_weights_sum, "grad_weights_sum"); on_gpu(grad_image, "grad_image"); on_gpu(sigmas, "sigmas"); on_gpu(rgbs, "rgbs");
-    c10::hip::HIPGuard g(sigmas.device());
+    device_guard g(sigmas.device());
     ok(ngp_composite_rays_train_backward(ptr<float>(grad_weights_sum), ptr<float>(grad_image), ptr<float>(sigmas), ptr<float>(rgbs), ptr<float>(deltas),
                                          ptr<int32_t>(rays), ptr<float>(weights_sum), ptr<float>(image), M, N, ptr<float>(grad_sigmas),
                                          ptr<float>(grad_rgbs), stream_of(sigmas)), "composite_rays_train_backward");
@@ -69,7 +69,7 @@ void march_rays(const uint32_t n_alive, const uint32_t n_step, const at::Tensor 
                 const at::Tensor grid, const at::Tensor nears, const at::Tensor fars, at::Tensor xyzs, at::Tensor dirs, at::Tensor deltas,
                 const uint32_t perturb) {
     on_gpu(rays_alive, "rays_alive"); on_gpu(rays_t, "rays_t"); on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(grid, "grid");
-    c10::hip::HIPGuard g(rays_o.device());
+    device_guard g(rays_o.device());
     ok(ngp_march_rays(n_alive, n_step, ptr<int32_t>(rays_alive), ptr<float>(rays_t), ptr<float>(rays_o), ptr<float>(rays_d), bound, dt_gamma, max_steps,
                       C, H, ptr<uint8_t>(grid), ptr<float>(nears), ptr<float>(fars), ptr<float>(xyzs), ptr<float>(dirs), ptr<float>(deltas), perturb,
                       stream_of(rays_o)), "march_rays");
@@ -78,7 +78,7 @@ void march_rays(const uint32_t n_alive, const uint32_t n_step, const at::Tensor 
 void composite_rays(const uint32_t n_alive, const uint32_t n_step, at::Tensor rays_alive, at::Tensor rays_t, at::Tensor sigmas, at::Tensor rgbs,
                     at::Tensor deltas, at::Tensor weights_sum, at::Tensor depth, at::Tensor image) {
     on_gpu(rays_alive, "rays_alive"); on_gpu(rays_t, "rays_t"); on_gpu(sigmas, "sigmas"); on_gpu(rgbs, "rgbs"); on_gpu(image, "image");
-    c10::hip::HIPGuard g(sigmas.device());
+    device_guard g(sigmas.device());
     ok(ngp_composite_rays(n_alive, n_step, ptr<int32_t>(rays_alive), ptr<float>(rays_t), ptr<float>(sigmas), ptr<float>(rgbs), ptr<float>(deltas),
                           ptr<float>(weights_sum), ptr<float>(depth), ptr<float>(image), stream_of(sigmas)), "composite_rays");
 }

@@ -4,15 +4,18 @@
 // Plain C++ (no .cu / .hip source, nothing hipified): every kernel lives in libngp_hip.so.
 #pragma once
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// PyTorch-ROCm presents its HIP devices under the device type "cuda"; the guard / stream classes for that are the *MasqueradingAsCUDA ones
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "../../include/ngp_hip.h"
 
 namespace shim {
 
 // torch's current stream on the tensor's device (the reference launched on the legacy default stream: SURVEY 8b)
-inline void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+inline void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
+
+using device_guard = c10::hip::HIPGuardMasqueradingAsCUDA;
 
 inline void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", ngp_last_error()); }
 

@@ -491,11 +491,23 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
 // inference march / composite
 // ---------------------------------------------------------------------------
 
+// FILL: the kernel also writes the zeros the reference gets from torch.zeros (raymarching.py:327-329): the slots a ray does not
+// reach (zero delta = terminated, raymarching.cu:867) and the alignment rows [n_alive * n_step, M); the buffers need no pre-zeroing.
+template <bool FILL>
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
                                                          const float* __restrict__ rays_t, march_args a,
                                                          float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
     // reference: raymarching.cu:707-814
     const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
+    if (FILL) {
+        // a.M rows in all; rows past the last ray's slots are spread over the launch's lanes
+        const uint64_t used = (uint64_t)n_alive * n_step;
+        for (uint64_t r = used + n; r < a.M; r += (uint64_t)gridDim.x * RM_RAY_BLOCK) {
+            xyzs[3 * r] = 0.f; xyzs[3 * r + 1] = 0.f; xyzs[3 * r + 2] = 0.f;
+            dirs[3 * r] = 0.f; dirs[3 * r + 1] = 0.f; dirs[3 * r + 2] = 0.f;
+            deltas[2 * r] = 0.f; deltas[2 * r + 1] = 0.f;
+        }
+    }
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     ngp_march_t m;
@@ -521,6 +533,14 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, u
             pl[0] = dt; pl[1] = t - last_t;
             last_t = t;
             px += 3; pd += 3; pl += 2; step++;
+        }
+    }
+    if (FILL) {
+        for (; step < n_step; step++) {
+            px[0] = 0.f; px[1] = 0.f; px[2] = 0.f;
+            pd[0] = 0.f; pd[1] = 0.f; pd[2] = 0.f;
+            pl[0] = 0.f; pl[1] = 0.f;
+            px += 3; pd += 3; pl += 2;
         }
     }
 }
@@ -559,19 +579,36 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_rays(uint32_t n_aliv
     image[3ll * index] = r; image[3ll * index + 1] = g; image[3ll * index + 2] = b;
 }
 
+static int march_rays_launch(bool fill, uint32_t M, uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                             const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                             uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                             float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
+    if ((n_alive == 0 || n_step == 0) && !(fill && M)) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas, "march_rays: null pointer");
+    NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
+    NGP_REQUIRE(!fill || (uint64_t)M >= (uint64_t)n_alive * n_step, "march_rays: M is smaller than n_alive * n_step");
+    march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, 0u, C, H, M, perturb};
+    const dim3 grid_dim(ngp_div_up(n_alive ? n_alive : 1, RM_RAY_BLOCK)), block(RM_RAY_BLOCK);
+    if (fill) hipLaunchKernelGGL(k_march_rays<true>, grid_dim, block, 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    else hipLaunchKernelGGL(k_march_rays<false>, grid_dim, block, 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    NGP_CHECK_LAUNCH("march_rays");
+    return NGP_OK;
+}
+
 extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                               const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                               uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                               float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
-    if (n_alive == 0 || n_step == 0) return NGP_OK;
-    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas, "march_rays: null pointer");
-    NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
-    if (n_alive == 0 || n_step == 0) return NGP_OK;
-    march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, 0u, C, H, 0u, perturb};
-    hipLaunchKernelGGL(k_march_rays, dim3(ngp_div_up(n_alive, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
-                       n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
-    NGP_CHECK_LAUNCH("march_rays");
-    return NGP_OK;
+    return march_rays_launch(false, 0, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
+                             xyzs, dirs, deltas, perturb, stream);
+}
+
+extern "C" int ngp_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                   uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                                   float* xyzs, float* dirs, float* deltas, uint32_t M, uint32_t perturb, void* stream) {
+    return march_rays_launch(true, M, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
+                             xyzs, dirs, deltas, perturb, stream);
 }
 
 extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,

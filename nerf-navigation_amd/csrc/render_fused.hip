@@ -38,6 +38,11 @@
 #endif
 static constexpr int RF_L = 16;       // levels (4 per lane group)
 static constexpr uint32_t RF_BLOCK = 256;
+// workgroups of k_field_forward_lds per CU.  Two 16-point tiles per pass need ~200 VGPRs: at 4 workgroups per CU (4 waves per SIMD,
+// 128 VGPRs) the kernel spilled 81 registers to scratch (400 B per lane); at 2 it has none (tests/test_build_options.py checks).
+#ifndef RF_FIELD_WG_PER_CU
+#define RF_FIELD_WG_PER_CU 2
+#endif
 #ifndef RF_PROBES_PER_ROUND
 #define RF_PROBES_PER_ROUND 512        // march iterations a round may spend so that every lane can collect its RV_S samples.
 #endif                                 // A/B on MI355X, ms per frame.  Before block skipping (each probe = one cell): 4: 26.0,
@@ -349,7 +354,7 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
     NGP_REQUIRE(xyzs && dirs && sigmas && rgbs, "field_forward: null pointer");
     const uint32_t npairs = (M + 31) >> 5;
     uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
-    if (blocks > 256 * 4) blocks = 256 * 4;            // four 36-KiB workgroups per CU
+    if (blocks > 256 * RF_FIELD_WG_PER_CU) blocks = 256 * RF_FIELD_WG_PER_CU;
     hipLaunchKernelGGL(k_field_forward_lds, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs);
     NGP_CHECK_LAUNCH("field_forward");
     return NGP_OK;
@@ -683,7 +688,7 @@ __device__ __forceinline__ void rv_activate(const rf_params& P, float& sigma, fl
 
 // ---------------------------------------------------------------------------
 // field_forward for explicit points (NeRFNetwork.forward in one launch): the frame kernel's field step on its own.
-// 256-thread workgroups, weights in LDS (36 KiB, so four workgroups share a CU), two 16-point tiles per pass.
+// 256-thread workgroups, weights in LDS (36 KiB each, RF_FIELD_WG_PER_CU workgroups share a CU), two 16-point tiles per pass.
 // ---------------------------------------------------------------------------
 template <bool FIXED>
 __device__ __forceinline__ void rf_points_loop(const rf_params& P, const rf_iter_class cls_rt, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w,
@@ -726,7 +731,7 @@ __device__ __forceinline__ void rf_points_loop(const rf_params& P, const rf_iter
     }
 }
 
-__global__ __launch_bounds__(RF_BLOCK, 4) void k_field_forward_lds(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
+__global__ __launch_bounds__(RF_BLOCK, RF_FIELD_WG_PER_CU) void k_field_forward_lds(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
                                                                     uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rf_smem);

@@ -119,7 +119,11 @@ class FFMLP(nn.Module):
 
     def forward(self, inputs):
         B, C = inputs.shape
-        pad = 128 - (B % 128)                          # always > 0: the reference pads a full 128 when B % 128 == 0
+        # The reference pads the batch past the next multiple of 128 with a torch.cat (ffmlp.py:157-159; a full 128 rows when B % 128 == 0)
+        # because its kernel works on 128-row blocks.  These kernels need a multiple of 32 only (forward 16, backward 32): batches that
+        # already are (every batch the march produces: align = 128) go in as they are -- the rows returned are the same, without
+        # copying the whole input.
+        pad = (32 - (B % 32)) % 32
         if pad > 0:
             inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
         outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,

@@ -25,6 +25,23 @@ RECOMPUTE_INPUT_GRAD = True
 RECOMPUTE_MIN_POINTS = 32768
 
 
+# The reference converts the float32 table to half on EVERY autocast forward (grid.py:38-39: 50 MB read + 25 MB written per call, 64
+# times per rendered frame).  The half copy is kept while the parameter is the same object with the same version counter, i.e. until an
+# optimiser step, load_state_dict or any in-place write changes it; training pays the conversion once per step as before.
+_HALF_TABLE = {"ref": None, "version": -1, "ptr": 0, "half": None}
+
+
+def _half_table(embeddings):
+    import weakref
+    c = _HALF_TABLE
+    if (c["ref"] is not None and c["ref"]() is embeddings and c["version"] == embeddings._version and c["ptr"] == embeddings.data_ptr()
+            and c["half"].device == embeddings.device):
+        return c["half"]
+    half = embeddings.detach().to(torch.half)
+    c.update(ref=weakref.ref(embeddings), version=embeddings._version, ptr=embeddings.data_ptr(), half=half)
+    return half
+
+
 class _grid_encode(Function):
     """reference: gridencoder/grid.py:19-87"""
 
@@ -41,7 +58,7 @@ class _grid_encode(Function):
         H = base_resolution
 
         if torch.is_autocast_enabled() and C % 2 == 0:
-            embeddings = embeddings.to(torch.half)
+            embeddings = _half_table(embeddings) if embeddings.dtype == torch.float32 else embeddings.to(torch.half)
         embeddings = embeddings.contiguous()
         if inputs.dtype != torch.float32:
             raise RuntimeError("inputs must be a float32 tensor")

@@ -210,13 +210,15 @@ class _march_rays(Function):
         M = n_alive * n_step
         if align > 0:
             M += align - (M % align)
-        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=rays_o.device)
-        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=rays_o.device)
-        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=rays_o.device)
-        _hip.check(_hip.lib().ngp_march_rays(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t), _hip.ptr(rays_o),
-                                             _hip.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _hip.ptr(density_bitfield),
-                                             _hip.ptr(near), _hip.ptr(far), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas),
-                                             int(perturb), _hip.stream()), "march_rays")
+        # the reference allocates with torch.zeros (three fill launches per loop iteration); here the march kernel writes the
+        # zeros of the slots no ray reaches and of the alignment rows itself (ngp_march_rays_fill): same contents, one launch
+        xyzs = torch.empty(M, 3, dtype=rays_o.dtype, device=rays_o.device)
+        dirs = torch.empty(M, 3, dtype=rays_o.dtype, device=rays_o.device)
+        deltas = torch.empty(M, 2, dtype=rays_o.dtype, device=rays_o.device)
+        _hip.check(_hip.lib().ngp_march_rays_fill(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t), _hip.ptr(rays_o),
+                                                  _hip.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _hip.ptr(density_bitfield),
+                                                  _hip.ptr(near), _hip.ptr(far), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas),
+                                                  M, int(perturb), _hip.stream()), "march_rays")
         return xyzs, dirs, deltas
 
 

@@ -42,3 +42,21 @@ def test_no_single_rounding_conversions_in_the_shipped_kernels(tmp_path):
     with ThreadPoolExecutor(max_workers=4) as pool:
         counts = dict(pool.map(isa, files))
     assert all(v == 0 for v in counts.values()), counts
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_fused_kernels_do_not_spill(tmp_path):
+    """The two kernels of the fused path must keep their working set in registers: a spill puts scratch loads and stores in the tile loop
+    (k_field_forward_lds once spilled 81 VGPRs = 400 B of scratch per lane at 4 workgroups per CU)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernels
+    src = os.path.join(ROOT, "nerf-navigation_amd", "csrc", "render_fused.hip")
+    flags = [f for f in FLAGS if f not in ("-O1", "-c", "-Werror")] + ["-O3", "-S"]
+    out = subprocess.run([HIPCC] + flags + [src, "-o", str(tmp_path / "rf.s")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = {k["name"]: k for k in kernels(open(tmp_path / "rf.s").read())}
+    field = next(v for n, v in res.items() if "k_field_forward_lds" in n)
+    frame = next(v for n, v in res.items() if "k_render_frame_multi" in n)
+    assert field["spill"] == 0 and frame["spill"] == 0, (field, frame)
+    assert field["vgpr"] <= 256 and frame["vgpr"] <= 256
