@@ -176,7 +176,17 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
             // x + y*s1 + z*s2 (always < size); the x-neighbour is the next row: one 8-byte load per (y, z)
             const uint32_t o00 = __umul24(gz, lv.s2b[i]) + (__umul24(gy, lv.s1b[i]) + ((gx << 2) + lv.base4[i]));
             const uint32_t o01 = o00 + lv.s1b[i], o10 = o00 + lv.s2b[i], o11 = o01 + lv.s2b[i];
+#ifdef RV_EXPERIMENT_FREE_LEVELS   // timing-only build (wrong image): the gathers of levels 0 .. RV_EXPERIMENT_FREE_LEVELS-1 are not issued at all --
+            // an upper bound on what serving those levels from LDS could gain (an LDS read cannot be cheaper than no read)
+            // (level 0 keeps its constant-one second feature, which the bench model's density logit reads: same densities, same sample count)
+            const uint32_t cst = ((threadIdx.x & 63u) >> 4) == 0u ? 0x3C000000u : 0u;
+            rf_row2 r0 = {cst, cst}, r1 = {cst, cst}, r2 = {cst, cst}, r3 = {cst, cst};
+            if (i != 0 || (int)((threadIdx.x & 63u) >> 4) >= RV_EXPERIMENT_FREE_LEVELS) {
+                r0 = rf_rows(P, o00); r1 = rf_rows(P, o01); r2 = rf_rows(P, o10); r3 = rf_rows(P, o11);
+            }
+#else
             const rf_row2 r0 = rf_rows(P, o00), r1 = rf_rows(P, o01), r2 = rf_rows(P, o10), r3 = rf_rows(P, o11);
+#endif
             raw[i & 1][0] = r0.lo; raw[i & 1][1] = r0.hi; raw[i & 1][2] = r1.lo; raw[i & 1][3] = r1.hi;
             raw[i & 1][4] = r2.lo; raw[i & 1][5] = r2.hi; raw[i & 1][6] = r3.lo; raw[i & 1][7] = r3.hi;
         } else {
