@@ -291,6 +291,53 @@ int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const f
                      float* image, float* depth, float* weights_sum, uint32_t* stats,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* Navigation-loop queries (BASELINE config 4), fused float32: the DEFAULT field of nerf/network.py                   */
+/* (hash grid 16 x 2 f32 -> Linear(32,64) -> Linear(64,16) ; SH16 ++ geo15 -> Linear(31,64) -> Linear(64,64) ->      */
+/* Linear(64,3), bias-free) as the planner and the pose filter call it: simulate.py:340-347.                          */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    const float* embeddings;     /* [sO,2] f32 (GridEncoder.embeddings) */
+    const int32_t* offsets_host; /* [L+1] i32 on the HOST */
+    const float* sigma_w0;       /* sigma_net.0.weight [64,32] */
+    const float* sigma_w1;       /* sigma_net.1.weight [16,64] */
+    const float* color_w0;       /* color_net.0.weight [64,31] */
+    const float* color_w1;       /* color_net.1.weight [64,64] */
+    const float* color_w2;       /* color_net.2.weight [3,64] */
+    uint32_t L;                  /* 16 */
+    uint32_t H;                  /* base resolution */
+    float S;                     /* log2(per_level_scale) */
+    float bound;
+    float density_scale;         /* NeRFRenderer.density_scale (nerf/renderer.py:208) */
+} ngp_nav_field_t;
+
+/* Transposed copies of sigma_w0 and color_w1 the kernels read (ngp_nav_field_workspace() bytes, caller-owned, device); call again
+ * whenever those weights change.  Every entry point below takes the same `prepared` pointer. */
+size_t ngp_nav_field_workspace(void);
+int ngp_nav_field_prepare(const ngp_nav_field_t* field_host, void* workspace, size_t workspace_bytes, void* stream);
+
+/* NeRFNetwork.density (nerf/network.py:125-143) on explicit points: sigma [M] = exp(h0) (trunc_exp), geo [M,15] = h[1:16] (may be NULL). */
+int ngp_nav_density_forward(const ngp_nav_field_t* field_host, const void* prepared, const float* xyz, uint32_t M, float* sigma, float* geo,
+                            void* stream);
+/* its backward to the points: grad_sigma [M], grad_geo [M,15] or NULL -> grad_xyz [M,3] (fully written; trunc_exp's clamped backward,
+ * activation.py:16-18; zero outside [-bound, bound]^3 like the encoder's dy_dx). */
+int ngp_nav_density_backward(const ngp_nav_field_t* field_host, const void* prepared, const float* xyz, uint32_t M, const float* grad_sigma,
+                             const float* grad_geo, float* grad_xyz, void* stream);
+
+/* NeRFRenderer.run (nerf/renderer.py:125-254) with upsample_steps = 0 and perturb = False, one workgroup per ray: nears, fars [N] from
+ * ngp_near_far_from_aabb; aabb [6] and bg_color [3] on the host; image [N,3] (background mixed in), depth [N], weights_sum [N].
+ * saved: NULL, or ngp_nav_run_saved_bytes(N, num_steps) bytes (108 per sample) that the forward fills for ngp_nav_run_backward. */
+size_t ngp_nav_run_saved_bytes(uint32_t N, uint32_t num_steps);
+int ngp_nav_run_forward(const ngp_nav_field_t* field_host, const void* prepared, const float* rays_o, const float* rays_d, const float* nears,
+                        const float* fars, uint32_t N, uint32_t num_steps, const float* aabb_host, const float* bg_color3_host,
+                        float* image, float* depth, float* weights_sum, void* saved, size_t saved_bytes, void* stream);
+/* its backward to the rays (what the pose filter differentiates, nav/estimator_helpers.py:316): grad_image [N,3], grad_depth [N] or NULL,
+ * grad_weights_sum [N] or NULL, the forward's `saved` buffer -> grad_rays_o, grad_rays_d [N,3] (fully written). */
+int ngp_nav_run_backward(const ngp_nav_field_t* field_host, const void* prepared, const float* rays_o, const float* rays_d, const float* nears,
+                         const float* fars, uint32_t N, uint32_t num_steps, const float* aabb_host, const float* bg_color3_host,
+                         const float* grad_image, const float* grad_depth, const float* grad_weights_sum, const void* saved, size_t saved_bytes,
+                         float* grad_rays_o, float* grad_rays_d, void* stream);
+
 /* ---- camera rays (reference: get_rays, nerf/utils.py:53-116) ----
  * pose: host, row-major 4x4 (or the first 3 rows of it) camera-to-world; intrinsics: host [4] = fx, fy, cx, cy.
  * Ray k is that of pixel inds[k] (device int64, row-major pixel index, the `inds` of the reference's random branches) or

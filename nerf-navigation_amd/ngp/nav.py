@@ -159,3 +159,167 @@ class GraphedDensity:
             raise ValueError(f"GraphedDensity was captured for {self.n} points, got {x.numel() // 3}")
         flat = x.reshape(self.n, 3)
         return _GraphedPointwise.apply(flat, self).reshape(x.shape[:-1])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the same queries on the fused float32 kernels of csrc/nav_field.hip: one launch forward, one launch backward
+# ------------------------------------------------------------------------------------------------------------------------
+class _NativeField:
+    """ngp_nav_field_t + the prepared (transposed) weights for a default-architecture field (ngp.field.NGPField: nn.Linear layers,
+    32-64-16 | 31-64-64-3, 16 x 2 hash grid).  Rebuilt when a parameter's storage or version changes."""
+
+    def __init__(self, renderer):
+        import ctypes
+        import numpy as np
+        import ngp_hip as _hip
+        self._hip, self._ct, self._np = _hip, ctypes, np
+        self.renderer = renderer
+        self.field = renderer.field
+        f = self.field
+        ok = (hasattr(f.sigma_net, "__len__") and len(f.sigma_net) == 2 and len(f.color_net) == 3
+              and tuple(f.sigma_net[0].weight.shape) == (64, 32) and tuple(f.sigma_net[1].weight.shape) == (16, 64)
+              and tuple(f.color_net[0].weight.shape) == (64, 31) and tuple(f.color_net[1].weight.shape) == (64, 64)
+              and tuple(f.color_net[2].weight.shape) == (3, 64) and f.encoder.num_levels == 16 and f.encoder.level_dim == 2
+              and f.encoder.input_dim == 3 and f.encoder.gridtype == "hash" and not f.encoder.align_corners
+              and f.encoder.embeddings.dtype == torch.float32)
+        if not ok:
+            raise RuntimeError("the fused nav queries support the default field only (hash grid 16 x 2 float32, Linear 32-64-16 | 31-64-64-3)")
+        self._key = None
+        self._offsets = (ctypes.c_int32 * 17)(*[int(v) for v in f.encoder.offsets.cpu().tolist()])
+
+    def _params(self):
+        f = self.field
+        return [f.encoder.embeddings, f.sigma_net[0].weight, f.sigma_net[1].weight, f.color_net[0].weight, f.color_net[1].weight, f.color_net[2].weight]
+
+    def struct(self):
+        """(ngp_nav_field_t, prepared-weights tensor); the transposes are redone only when a parameter changed"""
+        _hip, ct = self._hip, self._ct
+        ps = self._params()
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (float(self.field.bound), float(self.renderer.density_scale))
+        if key != self._key:
+            dev = ps[0].device
+            for p in ps:
+                if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
+                    raise RuntimeError("the fused nav queries need contiguous float32 parameters on the GPU")
+            L = _hip.lib()
+            self._prep = _hip.workspace(L.ngp_nav_field_workspace(), dev)
+            self._struct = _hip.ngp_nav_field_t(ps[0].data_ptr(), ct.cast(self._offsets, ct.c_void_p), ps[1].data_ptr(), ps[2].data_ptr(),
+                                                ps[3].data_ptr(), ps[4].data_ptr(), ps[5].data_ptr(), 16, self.field.encoder.base_resolution,
+                                                float(self._np.log2(self.field.encoder.per_level_scale)), float(self.field.bound),
+                                                float(self.renderer.density_scale))
+            with torch.cuda.device(dev):
+                _hip.check(L.ngp_nav_field_prepare(ct.byref(self._struct), _hip.ptr(self._prep), self._prep.numel(), _hip.stream()), "nav_field_prepare")
+            self._key = key
+        return self._struct, self._prep
+
+
+class _nav_density(torch.autograd.Function):
+    """sigma = trunc_exp(h0(x)) for [M,3] points in one launch; backward to the points in one launch (ngp_nav_density_*).  Like the
+    reference's encoder backward this is a first-order op: no graph is built through the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        import ctypes
+        import ngp_hip as _hip
+        x = x.contiguous().float()
+        M = x.shape[0]
+        sigma = torch.empty(M, dtype=torch.float32, device=x.device)
+        st, prep = owner.struct()
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib().ngp_nav_density_forward(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(x), M, _hip.ptr(sigma), None, _hip.stream()),
+                       "nav_density_forward")
+        ctx.save_for_backward(x)
+        ctx.owner = owner
+        return sigma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_sigma):
+        import ctypes
+        import ngp_hip as _hip
+        (x,) = ctx.saved_tensors
+        M = x.shape[0]
+        gx = torch.empty_like(x)
+        st, prep = ctx.owner.struct()
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib().ngp_nav_density_backward(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(x), M, _hip.ptr(grad_sigma.contiguous().float()),
+                                                           None, _hip.ptr(gx), _hip.stream()), "nav_density_backward")
+        return gx, None
+
+
+class _nav_run(torch.autograd.Function):
+    """NeRFRenderer.run(num_steps, upsample_steps = 0, perturb = False) for [N,3] rays: one launch forward, one backward to the rays."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, owner, num_steps, bg):
+        import ctypes
+        import raymarching
+        import ngp_hip as _hip
+        rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
+        N = rays_o.shape[0]
+        ren = owner.renderer
+        aabb_t = ren._aabb()
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb_t, ren.min_near)
+        aabb = (ctypes.c_float * 6)(*[float(v) for v in aabb_t.tolist()])
+        bgc = (ctypes.c_float * 3)(*bg)
+        image = torch.empty(N, 3, dtype=torch.float32, device=rays_o.device)
+        depth = torch.empty(N, dtype=torch.float32, device=rays_o.device)
+        ws = torch.empty(N, dtype=torch.float32, device=rays_o.device)
+        st, prep = owner.struct()
+        L = _hip.lib()
+        # the per-sample record the backward consumes (108 B per sample); not kept when nobody will ask for a gradient
+        need = any(ctx.needs_input_grad[:2])
+        saved = _hip.workspace(L.ngp_nav_run_saved_bytes(N, int(num_steps)), rays_o.device) if need else None
+        with torch.cuda.device(rays_o.device):
+            _hip.check(L.ngp_nav_run_forward(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
+                                             N, int(num_steps), aabb, bgc, _hip.ptr(image), _hip.ptr(depth), _hip.ptr(ws),
+                                             _hip.ptr(saved), saved.numel() if need else 0, _hip.stream()), "nav_run_forward")
+        ctx.save_for_backward(rays_o, rays_d, nears, fars, saved if need else torch.empty(0, device=rays_o.device))
+        ctx.owner, ctx.num_steps, ctx.bg, ctx.aabb = owner, int(num_steps), bgc, aabb
+        return image, depth, ws
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_image, g_depth, g_ws):
+        import ctypes
+        import ngp_hip as _hip
+        rays_o, rays_d, nears, fars, saved = ctx.saved_tensors
+        N = rays_o.shape[0]
+        go, gd = torch.empty_like(rays_o), torch.empty_like(rays_d)
+        st, prep = ctx.owner.struct()
+        with torch.cuda.device(rays_o.device):
+            _hip.check(_hip.lib().ngp_nav_run_backward(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
+                                                       N, ctx.num_steps, ctx.aabb, ctx.bg, _hip.ptr(g_image.contiguous().float()),
+                                                       _hip.ptr(g_depth.contiguous().float()), _hip.ptr(g_ws.contiguous().float()),
+                                                       _hip.ptr(saved), saved.numel(), _hip.ptr(go), _hip.ptr(gd), _hip.stream()), "nav_run_backward")
+        return go, gd, None, None, None
+
+
+class NativeNavQueries(NavQueries):
+    """NavQueries on the fused float32 kernels (csrc/nav_field.hip): `density_fn` = one launch (+ one for its gradient), `render_fn` = one
+    launch per max_ray_batch rays (+ one for the gradient to the rays) instead of ~130 launches per filter iteration.  Same interface and
+    the same results to float32 rounding (tests/test_gpu_nav_native.py compares both with the CPU oracle).  Needs the default field
+    (ngp.field.NGPField) in float32 and upsample_steps == 0 (what simulate.py uses); anything else: use NavQueries."""
+
+    def __init__(self, renderer, intrinsics, H, W, num_steps=512, upsample_steps=0, max_ray_batch=4096, freeze=True):
+        super().__init__(renderer, intrinsics, H, W, num_steps=num_steps, upsample_steps=upsample_steps, max_ray_batch=max_ray_batch, freeze=freeze)
+        if upsample_steps != 0:
+            raise ValueError("NativeNavQueries implements upsample_steps == 0 (the navigation configuration); use NavQueries otherwise")
+        self.native = _NativeField(self.renderer)
+        self.num_steps, self.max_ray_batch = int(num_steps), int(max_ray_batch)
+
+    def density_fn(self, x):
+        pts = x.reshape(-1, 3) @ self._rot_on(x.device)
+        return _nav_density.apply(pts, self.native).reshape(x.shape[:-1])
+
+    def render_fn(self, rays_o, rays_d):
+        """rays [B, N, 3] -> {'image' [B,N,3], 'depth' [B,N]} like NeRFRenderer.render(staged=True, bg_color=1, perturb=False)"""
+        B, N = rays_o.shape[:2]
+        images, depths = [], []
+        for b in range(B):
+            for head in range(0, N, self.max_ray_batch):
+                tail = min(head + self.max_ray_batch, N)
+                img, dep, _ = _nav_run.apply(rays_o[b, head:tail], rays_d[b, head:tail], self.native, self.num_steps, (1.0, 1.0, 1.0))
+                images.append(img)
+                depths.append(dep)
+        return {"image": torch.cat(images).view(B, N, 3), "depth": torch.cat(depths).view(B, N)}

@@ -68,6 +68,13 @@ _SIGNATURES = {
     "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_grid_encode_backward_inputs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_vp, c_u32, c_int, c_int, c_vp]),
+    "ngp_nav_field_workspace": (c_sz, []),
+    "ngp_nav_field_prepare": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "ngp_nav_density_forward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_nav_density_backward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp]),
+    "ngp_nav_run_saved_bytes": (c_sz, [c_u32, c_u32]),
+    "ngp_nav_run_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_nav_run_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "ngp_get_rays": (c_int, [c_vp, c_vp, c_u32, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_render_frame_camera": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -80,6 +87,12 @@ class ngp_field_t(ctypes.Structure):
     """include/ngp_hip.h: ngp_field_t"""
     _fields_ = [("embeddings", c_vp), ("offsets", c_vp), ("sigma_weights", c_vp), ("color_weights", c_vp),
                 ("L", c_u32), ("H", c_u32), ("S", c_f32), ("bound", c_f32), ("density_scale", c_f32)]
+
+
+class ngp_nav_field_t(ctypes.Structure):
+    """include/ngp_hip.h: ngp_nav_field_t"""
+    _fields_ = [("embeddings", c_vp), ("offsets_host", c_vp), ("sigma_w0", c_vp), ("sigma_w1", c_vp), ("color_w0", c_vp), ("color_w1", c_vp),
+                ("color_w2", c_vp), ("L", c_u32), ("H", c_u32), ("S", c_f32), ("bound", c_f32), ("density_scale", c_f32)]
 
 
 def build(verbose=False):

@@ -24,7 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--torch-profile", action="store_true", help="print torch.profiler's kernel table for the filter iteration")
-ap.add_argument("--only", default="", help="comma list of: planner, filter, planner_frozen, filter_frozen, planner_graphed, planner_native, filter_native")
+ap.add_argument("--only", default="", help="comma list of: planner, filter, planner_frozen, filter_frozen, planner_graphed, planner_native, filter_native, planner_native_graphed")
 args = ap.parse_args()
 only = set(filter(None, args.only.split(",")))
 
@@ -124,5 +124,13 @@ if hasattr(nav, "NativeNavQueries"):
     if want("filter_native"):
         res["filter_native"] = timeit(filt_native, args.steps)
     print("native fused fp32 queries: (ii) %.3f ms   (iii) %.3f ms" % (res.get("planner_native", float("nan")), res.get("filter_native", float("nan"))))
+    if want("planner_native_graphed"):
+        dens_n = nav.GraphedDensity(nq, n_points=pts.numel() // 3)
+
+        def planner_native_graphed():
+            p = pts.clone().requires_grad_(True)
+            dens_n(p).sum().backward()
+        res["planner_native_graphed"] = timeit(planner_native_graphed, 10 * args.steps)
+        print("native queries, one graph replay per planner query: (ii) %.3f ms" % res["planner_native_graphed"])
 main = res.get("filter_native", res.get("filter_frozen", float("nan")))
 print(json.dumps({"metric": "nav-loop query times (BASELINE config 4), ms", "ms_per_step": main, "steps": args.steps, **{k: round(v, 4) for k, v in res.items()}}))
