@@ -29,7 +29,7 @@ GATHER_BYTES_PER_SAMPLE = 512          # 16 levels x 8 corners x 2 features x 2 
 MLP_FLOPS_PER_SAMPLE = 2 * (64 * (32 + 64 + 16) + 64 * (32 + 128 + 16))   # FFMLP shapes of nerf/network_ff.py
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_PEAK_TFLOPS = 2500.0              # dense f16 MFMA peak (MI355X_MICROARCH.md)
-GATHER_PEAK_GBS = 8600.0               # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows, 8.6 TB/s chip-wide
+LANE_ADDRESSES_PER_SAMPLE = 11 * 8 + 5 * 4   # per-lane gather addresses the texture path sees per ray-sample
 # distinct 64-byte lines one ray-sample touches: dense levels 0-4 read 4 x-pairs each (4 lines), hashed levels 5-15 read 8 entries
 # whose x-neighbours share a line 15 times out of 16 (4 + 1/4 lines): 5*4 + 11*4.25 = 66.75  (profiles/r13: 58-69 measured)
 LINES_PER_SAMPLE = 5 * 4 + 11 * 4.25
@@ -39,17 +39,35 @@ ATOMIC_PEAK_GBS = 1300.0               # MI355X_MICROARCH.md "Global float atomi
 SCATTER_BYTES_PER_POINT = 512          # 16 levels x 8 corners x 2 features x 2 B of half2 atomics (SURVEY 8d "training extra")
 
 
-def sources_sha16():
-    """hash of the kernel sources the built library comes from: profiles/<tag>_meta.json records it, so a PMC summary collected for
+FRAME_SOURCES = ("render_fused.hip", "ngp_device.h", "ngp_march.h", "ngp_mlp.h", "ngp_sh.h", "ngp_camera.h", "Makefile")   # what k_render_frame_multi is built from
+TRAIN_SOURCES = ("gridencoder.hip", "ngp_device.h", "Makefile")                                                              # ... and k_grid_backward
+
+
+def sources_sha16(files=FRAME_SOURCES):
+    """hash of the kernel sources a profiled kernel is built from: profiles/<tag>_meta.json records it, so a PMC summary collected for
     an older kernel cannot pass as this one's traffic"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "nerf-navigation_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")) or name == "Makefile":
-            h.update(open(os.path.join(csrc, name), "rb").read())
+    for name in files:
+        h.update(open(os.path.join(csrc, name), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "ngp_hip.h"), "rb").read())
     return h.hexdigest()[:16]
+
+
+def committed_counters(pattern, files):
+    """per-dispatch PMC means of the newest committed profile matching `pattern`, or (None, reason) when it was collected for other sources"""
+    import csv
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not found:
+        return None, {"reason": "no committed profile"}
+    pmc = found[-1]
+    meta = pmc.replace("_pmc.csv", "_meta.json")
+    recorded = json.load(open(meta)).get("sources_sha16") if os.path.exists(meta) else None
+    if recorded != sources_sha16(files):
+        return None, {"profile": os.path.relpath(pmc, ROOT), "profile_sources": recorded, "built_sources": sources_sha16(files)}
+    return {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(pmc))}, {"profile": os.path.relpath(pmc, ROOT)}
 
 
 def bench_train(args, rank, world, dev, W, teacher):
@@ -119,9 +137,17 @@ def bench_train(args, rank, world, dev, W, teacher):
             if not ms:
                 return None
             a = SCATTER_BYTES_PER_POINT * pts / (ms * 1e-3) / 1e9
-            return {"bound": "atomic", "kernel": "k_grid_backward<half,3,2>", "achieved": a, "peak": ATOMIC_PEAK_GBS, "unit": "GB/s",
-                    "frac": a / ATOMIC_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
-                    "algorithmic_bytes_per_point": SCATTER_BYTES_PER_POINT, "points_per_launch": pts}
+            r = {"bound": "atomic", "kernel": "k_grid_backward<half,3,2>", "achieved": a, "peak": ATOMIC_PEAK_GBS, "unit": "GB/s",
+                 "frac": a / ATOMIC_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                 "algorithmic_bytes_per_point": SCATTER_BYTES_PER_POINT, "points_per_launch": pts,
+                 # the 1.3 TB/s peak is for 256 contiguous bytes per wave instruction; a hash-grid scatter is one 64-byte request per lane pair
+                 # (the guide: "64 lanes in 64 different rows ~17x slower"), i.e. ~20 G requests/s chip-wide is the ceiling that applies
+                 "scattered_request_peak_G_per_s": 20.0}
+            c, info = committed_counters("r[0-9][0-9]_train_pmc.csv", TRAIN_SOURCES)
+            if c is not None and c.get("WRITE_SIZE"):
+                r["profile"] = info["profile"]
+                r["profiled_requests_per_launch"] = c["WRITE_SIZE"] * 1024.0 / 64.0
+            return r
         print(json.dumps({
             "metric": "training rays/sec (4096-ray steps, FFMLP field under autocast, Adam, grid refresh every 16 steps)",
             "value": rays_all / t_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -312,39 +338,35 @@ def main():
             "algorithmic_bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
             "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,
             "mfma_frac": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12 / MFMA_PEAK_TFLOPS,
-            # second ceiling: the table is Infinity-Cache / L2 resident and read by scattered gathers, so the HBM figure above
-            # is not what bounds the kernel.  The guide's random-row gather from a 38 MB table reaches 8.6 TB/s with 1,152-B rows;
-            # here a "row" is one 4-byte (hashed levels) or 8-byte (dense x-pair) entry of a 64-byte line, i.e. the useful fraction
-            # of every line fetched is 1/16..1/8: the same line rate moves at most 8.6 TB/s x (512 B useful / 4,864 B of lines per sample).
-            "gather_ceiling": {"lines_per_sample": LINES_PER_SAMPLE, "line_bytes": 64,
-                               "line_rate_achieved_GBs": LINES_PER_SAMPLE * 64 * samples_per_launch / avg_kernel_s / 1e9,
-                               "line_rate_peak_GBs": GATHER_PEAK_GBS,
-                               "frac": LINES_PER_SAMPLE * 64 * samples_per_launch / avg_kernel_s / 1e9 / GATHER_PEAK_GBS},
+            # second ceiling: the 25 MB table is Infinity-Cache / L2 resident and read by scattered 4- and 8-byte gathers, so
+            # HBM is not what bounds the kernel.  What the texture path processes is lane addresses: 108 per ray-sample (11 hashed levels x 8
+            # + 5 dense levels x 4 x-pairs).  The guide documents no peak for that unit; `busy_units` (from the committed PMC profile of these
+            # sources) gives the measured busy fractions of TA / TD / VALU instead.
+            "gather": {"lane_addresses_per_sample": LANE_ADDRESSES_PER_SAMPLE,
+                       "achieved_G_lane_addresses_per_s": LANE_ADDRESSES_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e9,
+                       "l2_line_bytes_per_sample_upper_bound": LINES_PER_SAMPLE * 64},
         },
     }
 
     # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the figure comes from the
     # committed rocprofv3 --pmc passes of THIS command (tools/profile_round.sh -> profiles/<tag>_pmc.csv):
     # (FETCH_SIZE + WRITE_SIZE) KiB.  The loads are 4-byte scattered gathers, so the guide's 2x correction for wide
-    # coalesced streams does not apply (FETCH_SIZE == TCC_EA0_RDREQ x 64 B in the same profile).
-    try:
-        import csv
-        import glob
-        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))[-1]
-        c = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(pmc))}
-        meta = pmc.replace("_pmc.csv", "_meta.json")
-        recorded = json.load(open(meta)).get("sources_sha16") if os.path.exists(meta) else None
-        if args.path == "fused" and args.res == 800 and args.workload == "ring" and not strong:
-            if recorded == sources_sha16():
-                result["roofline"]["traffic"] = (c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
-                result["roofline"]["traffic_unit"] = "bytes per launch (L2-miss / fabric side; table is Infinity-Cache resident)"
-                result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
-            else:
-                # the committed counters were collected for other kernel sources than the ones built here: not this kernel's traffic
-                result["roofline"]["traffic_stale"] = {"profile": os.path.relpath(pmc, ROOT), "profile_sources": recorded,
-                                                       "built_sources": sources_sha16()}
-    except (IndexError, KeyError, OSError, ValueError):
-        pass
+    # coalesced streams does not apply (FETCH_SIZE == TCC_EA0_RDREQ x 64 B in the same profile).  The profile records a hash
+    # of the kernel's sources; counters of other sources are refused (traffic stays null).
+    if args.path == "fused" and args.res == 800 and args.workload == "ring" and not strong:
+        c, info = committed_counters("r[0-9][0-9]_pmc.csv", FRAME_SOURCES)
+        if c is not None and "FETCH_SIZE" in c:
+            result["roofline"]["traffic"] = (c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
+            result["roofline"]["traffic_unit"] = "bytes per launch (L2-miss / fabric side; table is Infinity-Cache resident)"
+            result["roofline"]["traffic_source"] = info["profile"]
+            if c.get("GRBM_GUI_ACTIVE") and c.get("TA_TA_BUSY_sum"):
+                cu_cycles = c["GRBM_GUI_ACTIVE"] * 256.0
+                result["roofline"]["busy_units"] = {"source": info["profile"], "ta_busy_frac": c["TA_TA_BUSY_sum"] / cu_cycles,
+                                                    "td_busy_frac": c.get("TD_TD_BUSY_sum", 0.0) / cu_cycles,
+                                                    "valu_busy_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cu_cycles * 4.0) if c.get("SQ_ACTIVE_INST_VALU") else None,
+                                                    "note": "what binds the kernel: the texture path and the VALU, not a memory level"}
+        else:
+            result["roofline"]["traffic_stale"] = info
 
     if not args.no_cpu and world == 1:
         from oracle import ngp_oracle as O, render_oracle as R

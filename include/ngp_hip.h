@@ -105,11 +105,15 @@ int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
                    float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream);
 
 /* The same with the zero-initialisation of the wrapper (raymarching/raymarching.py:327-329) done by the kernel: xyzs, dirs [M,3],
- * deltas [M,2] need NOT be pre-zeroed; every row is written (M >= n_alive * n_step: the wrapper's padded row count). */
+ * deltas [M,2] need NOT be pre-zeroed; every row is written (M >= n_alive * n_step: the wrapper's padded row count).
+ * workspace (optional, ngp_march_rays_workspace(C, H) bytes): the call builds a coarse occupancy map (one bit per 4^3 block) in it and the
+ * march answers "block empty" from LDS instead of from the bitfield; same samples, bit for bit. */
+size_t ngp_march_rays_workspace(uint32_t C, uint32_t H);
 int ngp_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                         const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                         uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
-                        float* xyzs, float* dirs, float* deltas, uint32_t M, uint32_t perturb, void* stream);
+                        float* xyzs, float* dirs, float* deltas, uint32_t M, uint32_t perturb,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* raymarching.h:18 composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
  * mutates rays_alive (-1 = dead), rays_t, weights_sum, depth, image in place. */

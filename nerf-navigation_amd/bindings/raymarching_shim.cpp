@@ -70,9 +70,12 @@ void march_rays(const uint32_t n_alive, const uint32_t n_step, const at::Tensor 
                 const uint32_t perturb) {
     on_gpu(rays_alive, "rays_alive"); on_gpu(rays_t, "rays_t"); on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(grid, "grid");
     device_guard g(rays_o.device());
-    ok(ngp_march_rays(n_alive, n_step, ptr<int32_t>(rays_alive), ptr<float>(rays_t), ptr<float>(rays_o), ptr<float>(rays_d), bound, dt_gamma, max_steps,
-                      C, H, ptr<uint8_t>(grid), ptr<float>(nears), ptr<float>(fars), ptr<float>(xyzs), ptr<float>(dirs), ptr<float>(deltas), perturb,
-                      stream_of(rays_o)), "march_rays");
+    // the _fill form: the kernel writes every row (the reference wrapper's torch.zeros stays harmless) and answers "block empty" from a
+    // coarse occupancy map it builds in this workspace
+    at::Tensor ws = bytes_like(rays_o, ngp_march_rays_workspace(C, H));
+    ok(ngp_march_rays_fill(n_alive, n_step, ptr<int32_t>(rays_alive), ptr<float>(rays_t), ptr<float>(rays_o), ptr<float>(rays_d), bound, dt_gamma,
+                           max_steps, C, H, ptr<uint8_t>(grid), ptr<float>(nears), ptr<float>(fars), ptr<float>(xyzs), ptr<float>(dirs),
+                           ptr<float>(deltas), (uint32_t)xyzs.size(0), perturb, ws.data_ptr(), (size_t)ws.numel(), stream_of(rays_o)), "march_rays");
 }
 
 void composite_rays(const uint32_t n_alive, const uint32_t n_step, at::Tensor rays_alive, at::Tensor rays_t, at::Tensor sigmas, at::Tensor rgbs,

@@ -176,6 +176,8 @@ struct ngp_march_t {
     uint32_t c_blk, c_lo, c_hi;       // the block whose word is cached, and the word
     float skip_M;                     // per-ray margin of the verified skip (ngp_skip_margin); inf = never skip
     uint32_t s_blk, s_empty;          // the 16^3 block last examined and whether it is empty
+    const uint32_t* coarse;           // optional (LDS): one bit per 4^3 block, 1 = some cell of the block is occupied
+    uint32_t coarse_words;            // 32-bit words of it per cascade level
 
     __device__ __forceinline__ void setup(const float* o, const float* d, float bound_, float dt_gamma_,
                                           uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid_) {
@@ -195,6 +197,13 @@ struct ngp_march_t {
         c_blk = 0xffffffffu; c_lo = 0u; c_hi = 0u;
         skip_M = __builtin_inff();
         s_blk = 0xffffffffu; s_empty = 0u;
+        coarse = nullptr; coarse_words = 0u;
+    }
+
+    // A coarse occupancy map (csrc/raymarching.hip: k_rm_build_coarse, staged in LDS by the kernel) answers "is this 4^3 / 16^3 block
+    // empty" without touching the bitfield: the empty part of a ray costs no dependent global load at all.
+    __device__ __forceinline__ void use_coarse(const uint32_t* lds_coarse, uint32_t words_per_level) {
+        if (blocks_per_level && lds_coarse) { coarse = lds_coarse; coarse_words = words_per_level; }
     }
 
     // enable verified block skipping for this ray (call after setup, once `far` is known)
@@ -228,7 +237,24 @@ struct ngp_march_t {
         x = r.x; y = r.y; z = r.z; dt = r.dt;
         const uint32_t mort = ngp_morton3((uint32_t)r.nx, (uint32_t)r.ny, (uint32_t)r.nz);
         bool occ, block_is_empty = false;
-        if (blocks_per_level) {
+        bool super = false;
+        if (coarse) {
+            const uint32_t blk = mort >> 6;
+            const bool maybe = (coarse[(uint32_t)r.level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u;
+            if (maybe) {
+                const uint32_t gblk = (uint32_t)r.level * blocks_per_level + blk;
+                if (gblk != c_blk) {
+                    const uint2 w = reinterpret_cast<const uint2*>(grid)[gblk];
+                    c_blk = gblk; c_lo = w.x; c_hi = w.y;
+                }
+                occ = (((mort & 32u) ? c_hi : c_lo) >> (mort & 31u)) & 1u;
+            } else {
+                occ = false;
+                block_is_empty = true;
+                const uint32_t sw = (uint32_t)r.level * coarse_words + ((blk >> 6) << 1);       // the 64 coarse bits of the 16^3 block
+                super = (coarse[sw] | coarse[sw + 1]) == 0u;
+            }
+        } else if (blocks_per_level) {
             // the reference's bit (raymarching.cu:382-383) is bit (morton & 63) of word level * H^3 / 64 + (morton >> 6)
             const uint32_t gblk = (uint32_t)r.level * blocks_per_level + (mort >> 6);
             if (gblk != c_blk) {
@@ -244,7 +270,7 @@ struct ngp_march_t {
         if (occ) return true;
         const float tt = r.cell_exit(*this, tc);
         if (block_is_empty && skip_M < __builtin_inff()) {
-            const int sh = super_empty(r.level, mort) ? 4 : 2;
+            const int sh = (coarse ? super : super_empty(r.level, mort)) ? 4 : 2;
             const float ta = ngp_try_skip(*this, r, tc, tt, sh, skip_M);
             if (ta >= 0.0f) { t = ta; return false; }
         }

@@ -158,7 +158,54 @@ struct march_args {
     const float* nears; const float* fars;
     float bound, dt_gamma;
     uint32_t max_steps, N, C, H, M, perturb;
+    const uint32_t* coarse = nullptr;   // optional coarse occupancy map (global; the kernels stage it in LDS), one bit per 4^3 block
+    uint32_t coarse_words = 0;         // 32-bit words per cascade level (H^3 / 64 / 32)
 };
+
+// coarse[w] bit i = any cell of Morton block 32 w + i (64 cells = one aligned 64-bit word of the bitfield) is occupied
+__global__ __launch_bounds__(RM_BLOCK) void k_rm_build_coarse(const uint8_t* __restrict__ bitfield, uint32_t n_blocks_total,
+                                                              uint32_t* __restrict__ coarse) {
+    const uint32_t w = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (w * 32 >= n_blocks_total) return;
+    const uint64_t* b64 = reinterpret_cast<const uint64_t*>(bitfield);
+    uint32_t bits = 0;
+    #pragma unroll 8
+    for (uint32_t i = 0; i < 32; i++) {
+        const uint32_t blk = w * 32 + i;
+        if (blk < n_blocks_total && b64[blk] != 0ull) bits |= 1u << i;
+    }
+    coarse[w] = bits;
+}
+
+static constexpr size_t RM_COARSE_MAX = 48 * 1024;                     // largest map the march kernels stage in LDS (H = 128: 4 KiB per cascade)
+
+// bytes of the coarse map for this grid, or 0 when it is not used (cell index not exact in binary32, H^3 / 64 not a multiple of 32,
+// misaligned bitfield, or too large for LDS): exactly the condition under which ngp_march_t caches 64-bit block words
+static size_t rm_coarse_bytes(const uint8_t* grid, uint32_t C, uint32_t H) {
+    const bool exact = (H & (H - 1u)) == 0u && H >= 16u && (uint64_t)C * H * H * H <= (1ull << 24) && (reinterpret_cast<uintptr_t>(grid) & 15u) == 0u;
+    if (!exact) return 0;
+    const size_t bytes = (size_t)C * ((size_t)H * H * H / 64) / 8;
+    return bytes <= RM_COARSE_MAX ? bytes : 0;
+}
+
+// builds the map into `dst` (device) and points the march arguments at it
+static void rm_attach_coarse(march_args& a, void* dst, hipStream_t s) {
+    const uint32_t n_blocks_total = a.C * (a.H * a.H * a.H / 64);
+    hipLaunchKernelGGL(k_rm_build_coarse, dim3(ngp_div_up(n_blocks_total / 32, RM_BLOCK)), dim3(RM_BLOCK), 0, s, a.grid, n_blocks_total, (uint32_t*)dst);
+    a.coarse = (const uint32_t*)dst;
+    a.coarse_words = a.H * a.H * a.H / 64 / 32;
+}
+
+// every thread of a RM_RAY_BLOCK workgroup calls this before marching: copies the map into dynamic LDS (or returns nullptr without one)
+__device__ __forceinline__ const uint32_t* rm_stage_coarse(const march_args& a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t rm_lds_coarse[];
+    if (!a.coarse) return nullptr;
+    const uint32_t nw = a.C * a.coarse_words;
+    for (uint32_t i = threadIdx.x * 4; i < nw; i += RM_RAY_BLOCK * 4)
+        *reinterpret_cast<uint4*>(rm_lds_coarse + i) = *reinterpret_cast<const uint4*>(a.coarse + i);
+    __syncthreads();
+    return rm_lds_coarse;
+}
 
 __device__ __forceinline__ float train_t0(const ngp_march_t& m, float near, uint32_t n, uint32_t perturb) {
     if (!perturb) return near;
@@ -195,11 +242,13 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
                                                                 const int* __restrict__ counter,
                                                                 uint32_t* __restrict__ block_sums, float* __restrict__ tbuf) {
     __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
+    const uint32_t* lds_coarse = rm_stage_coarse(a);
     const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     uint32_t num_steps = 0;
     if (n < a.N) {
         ngp_march_t m;
         m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+        m.use_coarse(lds_coarse, a.coarse_words);
         const float far = a.fars[n];
         m.allow_skip(a.C, a.H, far);
         float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
@@ -328,14 +377,14 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_fill(march_args a,
     }
 }
 
-extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) {
-    return sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4);
-}
+static size_t rm_train_ws_base(uint32_t N) { return (sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4) + 255) & ~(size_t)255; }
+
+// block sums and bases | room for a coarse occupancy map (built per call: the bitfield changes every 16 steps)
+extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) { return rm_train_ws_base(N) + RM_COARSE_MAX; }
 
 // The same plus room for every sample's t (N * max_steps floats): with it the second pass does not march again.
 extern "C" size_t ngp_march_rays_train_workspace_full(uint32_t N, uint32_t max_steps) {
-    const size_t base = (ngp_march_rays_train_workspace(N) + 255) & ~(size_t)255;
-    return base + sizeof(float) * (size_t)N * max_steps;
+    return ngp_march_rays_train_workspace(N) + sizeof(float) * (size_t)N * max_steps;
 }
 
 extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -355,8 +404,10 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
     hipStream_t s = (hipStream_t)stream;
     float* tbuf = nullptr;
     if (workspace_bytes >= ngp_march_rays_train_workspace_full(N, max_steps))
-        tbuf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + ((ngp_march_rays_train_workspace(N) + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, counter, block_sums, tbuf);
+        tbuf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + ngp_march_rays_train_workspace(N));
+    const size_t cbytes = rm_coarse_bytes(grid, C, H);
+    if (cbytes) rm_attach_coarse(a, reinterpret_cast<unsigned char*>(workspace) + rm_train_ws_base(N), s);
+    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, block_sums, tbuf);
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
     hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas, tbuf ? 1 : 0);
     if (tbuf) hipLaunchKernelGGL(k_march_train_fill, dim3(N), dim3(RM_RAY_BLOCK), 0, s, a, rays, bases, tbuf, xyzs, dirs, deltas);
@@ -498,6 +549,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, u
                                                          const float* __restrict__ rays_t, march_args a,
                                                          float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
     // reference: raymarching.cu:707-814
+    const uint32_t* lds_coarse = rm_stage_coarse(a);
     const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     if (FILL) {
         // a.M rows in all; rows past the last ray's slots are spread over the launch's lanes
@@ -512,6 +564,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, u
     const int index = rays_alive[n];
     ngp_march_t m;
     m.setup(a.rays_o + 3ll * index, a.rays_d + 3ll * index, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+    m.use_coarse(lds_coarse, a.coarse_words);
     float* px = xyzs + 3ull * n * n_step;
     float* pd = dirs + 3ull * n * n_step;
     float* pl = deltas + 2ull * n * n_step;
@@ -582,15 +635,20 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_rays(uint32_t n_aliv
 static int march_rays_launch(bool fill, uint32_t M, uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                              const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                              uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
-                             float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
+                             float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* workspace, size_t workspace_bytes, void* stream) {
     if ((n_alive == 0 || n_step == 0) && !(fill && M)) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas, "march_rays: null pointer");
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
     NGP_REQUIRE(!fill || (uint64_t)M >= (uint64_t)n_alive * n_step, "march_rays: M is smaller than n_alive * n_step");
     march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, 0u, C, H, M, perturb};
     const dim3 grid_dim(ngp_div_up(n_alive ? n_alive : 1, RM_RAY_BLOCK)), block(RM_RAY_BLOCK);
-    if (fill) hipLaunchKernelGGL(k_march_rays<true>, grid_dim, block, 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
-    else hipLaunchKernelGGL(k_march_rays<false>, grid_dim, block, 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    // the coarse map pays when rays cross empty space; it is rebuilt on every call (2 us: the bitfield may have changed, and a cache
+    // keyed on a pointer could go stale silently)
+    const size_t cbytes = (workspace && n_alive) ? rm_coarse_bytes(grid, C, H) : 0;
+    const size_t lds = (cbytes && workspace_bytes >= cbytes) ? cbytes : 0;
+    if (lds) rm_attach_coarse(a, workspace, (hipStream_t)stream);
+    if (fill) hipLaunchKernelGGL(k_march_rays<true>, grid_dim, block, lds, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    else hipLaunchKernelGGL(k_march_rays<false>, grid_dim, block, lds, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
     NGP_CHECK_LAUNCH("march_rays");
     return NGP_OK;
 }
@@ -600,16 +658,19 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
                               uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                               float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
     return march_rays_launch(false, 0, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
-                             xyzs, dirs, deltas, perturb, stream);
+                             xyzs, dirs, deltas, perturb, nullptr, 0, stream);
 }
 
 extern "C" int ngp_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                                    const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                                    uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
-                                   float* xyzs, float* dirs, float* deltas, uint32_t M, uint32_t perturb, void* stream) {
+                                   float* xyzs, float* dirs, float* deltas, uint32_t M, uint32_t perturb,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     return march_rays_launch(true, M, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
-                             xyzs, dirs, deltas, perturb, stream);
+                             xyzs, dirs, deltas, perturb, workspace, workspace_bytes, stream);
 }
+
+extern "C" size_t ngp_march_rays_workspace(uint32_t C, uint32_t H) { (void)C; (void)H; return RM_COARSE_MAX; }
 
 extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
                                   const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {

@@ -1452,12 +1452,9 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
 
 static inline bool rv_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
-static int rv_block_skip_enabled = 1;
-extern "C" int ngp_render_set_block_skip(int enabled) {
-    const int old = rv_block_skip_enabled;
-    rv_block_skip_enabled = enabled ? 1 : 0;
-    return old;
-}
+// process-wide validation switch; atomic because callers may render from several host threads (one stream each)
+static std::atomic<int> rv_block_skip_enabled{1};
+extern "C" int ngp_render_set_block_skip(int enabled) { return rv_block_skip_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 static constexpr size_t RV_WS_COARSE = 256, RV_WS_TILES = 256 + 48 * 1024;   // header: global queue + debug words | 8 band queues
 extern "C" size_t ngp_render_frame_workspace(uint32_t N) {
@@ -1543,7 +1540,7 @@ static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, c
         // block skipping needs the 16^3 blocks aligned with the cascade boundaries (cells H/4 and 3H/4 of the next level) and
         // every level's half-width a power of two: H a power of two >= 64, and bound a power of two unless there is one cascade
         int e;
-        F.skip = (rv_block_skip_enabled && Hgrid >= 64 && (C == 1 || frexpf(field_host->bound, &e) == 0.5f)) ? 1u : 0u;
+        F.skip = (rv_block_skip_enabled.load(std::memory_order_relaxed) && Hgrid >= 64 && (C == 1 || frexpf(field_host->bound, &e) == 0.5f)) ? 1u : 0u;
     }
     NGP_REQUIRE(lds <= 160 * 1024, "render_frame: LDS carve exceeds 160 KiB");
     F.tile_order = nullptr;

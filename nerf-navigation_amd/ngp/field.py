@@ -81,14 +81,23 @@ class NGPFieldFF(nn.Module):
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
         d = self.encoder_dir(d)
-        p = torch.zeros_like(geo_feat[..., :1])
-        h = self.color_net(torch.cat([d, geo_feat, p], dim=-1))
+        h = self.color_net(self._color_input(d, geo_feat))
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    @staticmethod
+    def _color_input(d, geo_feat):
+        """cat(SH16, geo15, one zero column) (network_ff.py:67-68).  The SH features are float32 and geo_feat is half under autocast: the
+        reference's cat promotes all 32 columns to float32 and FFMLP's cast_inputs=half rounds them back -- two full-width copies per
+        call (282 MB each at 2.2 M training points).  Rounding the 16 SH columns first and concatenating halves gives the same 32 halves."""
+        if geo_feat.dtype == torch.float16 and torch.is_autocast_enabled():
+            d = d.to(torch.float16)
+        p = torch.zeros_like(geo_feat[..., :1])
+        return torch.cat([d, geo_feat, p], dim=-1)
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         if mask is not None:
@@ -101,8 +110,7 @@ class NGPFieldFF(nn.Module):
                 return rgbs
             d, geo_feat = d.index_select(0, rows), geo_feat.index_select(0, rows)
         d = self.encoder_dir(d)
-        p = torch.zeros_like(geo_feat[..., :1])
-        h = torch.sigmoid(self.color_net(torch.cat([d, geo_feat, p], dim=-1)))
+        h = torch.sigmoid(self.color_net(self._color_input(d, geo_feat)))
         if mask is not None:
             return rgbs.index_copy(0, rows, h.to(rgbs.dtype))
         return h

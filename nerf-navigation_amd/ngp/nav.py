@@ -308,7 +308,19 @@ class NativeNavQueries(NavQueries):
         self.native = _NativeField(self.renderer)
         self.num_steps, self.max_ray_batch = int(num_steps), int(max_ray_batch)
 
+    # One lane evaluates one point through all 16 levels, so a small batch (the planner's 10,000 body points = 40 workgroups) is bound by
+    # that lane's 16 dependent gather round trips: below this many points the level-parallel op chain (NavQueries.density_fn, 0.15 ms as
+    # one hipGraph replay) is the faster route; the A* occupancy query (10^6 points, nav/quad_plot.py:65-79) and the filter are far above it.
+    NATIVE_MIN_POINTS = 32768
+
     def density_fn(self, x):
+        if x.numel() // 3 < self.NATIVE_MIN_POINTS:
+            return super().density_fn(x)
+        pts = x.reshape(-1, 3) @ self._rot_on(x.device)
+        return _nav_density.apply(pts, self.native).reshape(x.shape[:-1])
+
+    def density_fn_native(self, x):
+        """the fused kernels whatever the batch size (tests, timing)"""
         pts = x.reshape(-1, 3) @ self._rot_on(x.device)
         return _nav_density.apply(pts, self.native).reshape(x.shape[:-1])
 

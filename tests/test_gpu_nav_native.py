@@ -47,7 +47,7 @@ def test_native_density_value_and_gradient(model, dev):
     pts[0, :4] = [[2.5, 0, 0], [0, -2.2, 0.3], [1.999, 1.999, -1.999], [0, 0, 0]]            # two outside the bound-2 box
     w = rng.uniform(0.5, 1.5, size=(20, 500)).astype(np.float32)
     pg = t(pts, dev).requires_grad_(True)
-    sg = q.density_fn(pg)
+    sg = q.density_fn_native(pg)
     (sg * t(w, dev)).sum().backward()
     po = torch.from_numpy(pts).requires_grad_(True)
     so = orc.density(po.reshape(-1, 3) @ torch.tensor(nav.ROT))["sigma"].reshape(20, 500)
@@ -103,14 +103,17 @@ def test_graphed_native_density(model, dev):
     q = model["q"]
     rng = np.random.default_rng(4)
     pts = t(rng.uniform(-1, 1, size=(20, 500, 3)).astype(np.float32), dev)
-    dens = nav.GraphedDensity(q, n_points=10000)
+    class _Native:                                                           # GraphedDensity over the fused kernels whatever the batch size
+        renderer = q.renderer
+        density_fn = staticmethod(q.density_fn_native)
+    dens = nav.GraphedDensity(_Native, n_points=10000)
     for _ in range(2):                                                       # two replays: the static buffers are reused correctly
         pts = pts.roll(1, 0)
         a = pts.clone().requires_grad_(True)
         sa = dens(a)
         sa.sum().backward()
         b = pts.clone().requires_grad_(True)
-        sb = q.density_fn(b)
+        sb = q.density_fn_native(b)
         sb.sum().backward()
         assert torch.equal(sa, sb) and torch.equal(a.grad, b.grad)
 

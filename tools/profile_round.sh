@@ -15,7 +15,7 @@ if [ $# -eq 0 ]; then set -- bench.py --steps 30 --warmup 5 --no-cpu; fi
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 SCRIPT=$R/$1; shift
-python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.sources_sha16())" > $R/gpurun_out/${TAG}_sources.txt
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.sources_sha16(bench.FRAME_SOURCES), bench.sources_sha16(bench.TRAIN_SOURCES))" > $R/gpurun_out/${TAG}_sources.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -- python3 $SCRIPT "$@" > $R/gpurun_out/${TAG}_kt.log 2>&1
 echo "kernel trace done: $(grep -c . $R/gpurun_out/${TAG}_kt.log) log lines"

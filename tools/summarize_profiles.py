@@ -12,7 +12,6 @@ import argparse
 import collections
 import csv
 import glob
-import hashlib
 import json
 import os
 import sys
@@ -22,6 +21,7 @@ ap.add_argument("tag")
 ap.add_argument("kernels", nargs="*", default=["k_render_frame"])
 ap.add_argument("--title", default="bench.py, 800x800 S-ring, 1x MI355X")
 ap.add_argument("--top", type=int, default=0)
+ap.add_argument("--sources", default="frame", choices=["frame", "train"], help="which kernel's source set the recorded hash covers")
 args = ap.parse_args()
 tag = args.tag
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,14 +29,14 @@ src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+sys.path.insert(0, root)
+import bench  # noqa: E402  (sources_sha16 and the per-kernel source lists live there)
+
+SOURCE_SETS = {"frame": bench.FRAME_SOURCES, "train": bench.TRAIN_SOURCES}
+
+
 def sources_sha16():
-    h = hashlib.sha256()
-    csrc = os.path.join(root, "nerf-navigation_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")) or name == "Makefile":
-            h.update(open(os.path.join(csrc, name), "rb").read())
-    h.update(open(os.path.join(root, "include", "ngp_hip.h"), "rb").read())
-    return h.hexdigest()[:16]
+    return bench.sources_sha16(SOURCE_SETS[args.sources])
 
 
 def newest(pattern):
@@ -48,7 +48,7 @@ def newest(pattern):
 sha = sources_sha16()
 stamp = os.path.join(src, f"{tag}_sources.txt")
 if os.path.exists(stamp):
-    profiled = open(stamp).read().strip()
+    profiled = open(stamp).read().split()[0 if args.sources == "frame" else 1]
     if profiled != sha:
         sys.exit(f"refusing: {tag} was profiled with kernel sources {profiled}, this tree has {sha} (re-profile, or check out the profiled commit)")
 

@@ -24,7 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--torch-profile", action="store_true", help="print torch.profiler's kernel table for the filter iteration")
-ap.add_argument("--only", default="", help="comma list of: planner, filter, planner_frozen, filter_frozen, planner_graphed, planner_native, filter_native, planner_native_graphed")
+ap.add_argument("--only", default="", help="comma list of: planner, filter, planner_frozen, filter_frozen, planner_graphed, planner_native, filter_native, planner_native_graphed, astar")
 args = ap.parse_args()
 only = set(filter(None, args.only.split(",")))
 
@@ -114,7 +114,7 @@ if hasattr(nav, "NativeNavQueries"):
 
     def planner_native():
         p = pts.clone().requires_grad_(True)
-        nq.density_fn(p).sum().backward()
+        nq.density_fn_native(p).sum().backward()
 
     def filt_native():
         ro, rd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
@@ -125,12 +125,22 @@ if hasattr(nav, "NativeNavQueries"):
         res["filter_native"] = timeit(filt_native, args.steps)
     print("native fused fp32 queries: (ii) %.3f ms   (iii) %.3f ms" % (res.get("planner_native", float("nan")), res.get("filter_native", float("nan"))))
     if want("planner_native_graphed"):
-        dens_n = nav.GraphedDensity(nq, n_points=pts.numel() // 3)
+        class _N:
+            renderer = nq.renderer
+            density_fn = staticmethod(nq.density_fn_native)
+        dens_n = nav.GraphedDensity(_N, n_points=pts.numel() // 3)
 
         def planner_native_graphed():
             p = pts.clone().requires_grad_(True)
             dens_n(p).sum().backward()
         res["planner_native_graphed"] = timeit(planner_native_graphed, 10 * args.steps)
         print("native queries, one graph replay per planner query: (ii) %.3f ms" % res["planner_native_graphed"])
+if want("astar"):
+    big = torch.rand(1000000, 3, device=dev) * 2 - 1                       # the A* occupancy query: 100^3 lattice, no gradient (nav/quad_plot.py:65-79)
+    with torch.no_grad():
+        res["astar_torch"] = timeit(lambda: q.density_fn(big), args.steps)
+        if hasattr(nav, "NativeNavQueries"):
+            res["astar_native"] = timeit(lambda: nq.density_fn(big), args.steps)
+    print("A* query, 10^6 points, no gradient: op chain %.3f ms, fused %.3f ms" % (res["astar_torch"], res.get("astar_native", float("nan"))))
 main = res.get("filter_native", res.get("filter_frozen", float("nan")))
 print(json.dumps({"metric": "nav-loop query times (BASELINE config 4), ms", "ms_per_step": main, "steps": args.steps, **{k: round(v, 4) for k, v in res.items()}}))
