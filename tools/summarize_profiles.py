@@ -21,11 +21,12 @@ ap.add_argument("tag")
 ap.add_argument("kernels", nargs="*", default=["k_render_frame"])
 ap.add_argument("--title", default="bench.py, 800x800 S-ring, 1x MI355X")
 ap.add_argument("--top", type=int, default=0)
+ap.add_argument("--dst", default=None, help="output directory (default: profiles/ of the repository)")
 ap.add_argument("--sources", default="frame", choices=["frame", "train"], help="which kernel's source set the recorded hash covers")
 args = ap.parse_args()
 tag = args.tag
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+src, dst = os.path.join(root, "gpurun_out"), (args.dst or os.path.join(root, "profiles"))
 os.makedirs(dst, exist_ok=True)
 
 
