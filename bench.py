@@ -51,7 +51,6 @@ def sources_sha16(files=FRAME_SOURCES):
     csrc = os.path.join(ROOT, "nerf-navigation_amd", "csrc")
     for name in files:
         h.update(open(os.path.join(csrc, name), "rb").read())
-    h.update(open(os.path.join(ROOT, "include", "ngp_hip.h"), "rb").read())
     return h.hexdigest()[:16]
 
 
