@@ -359,10 +359,13 @@ def main():
             result["roofline"]["traffic_unit"] = "bytes per launch (L2-miss / fabric side; table is Infinity-Cache resident)"
             result["roofline"]["traffic_source"] = info["profile"]
             if c.get("GRBM_GUI_ACTIVE") and c.get("TA_TA_BUSY_sum"):
-                cu_cycles = c["GRBM_GUI_ACTIVE"] * 256.0
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; TA/TD busy over the 256 CUs; SQ_ACTIVE_INST_VALU counts quad-cycles over the
+                # 1,024 SIMDs (x4 = cycles): all three as fractions of the cycles their units had during the launch
+                cu_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
                 result["roofline"]["busy_units"] = {"source": info["profile"], "ta_busy_frac": c["TA_TA_BUSY_sum"] / cu_cycles,
                                                     "td_busy_frac": c.get("TD_TD_BUSY_sum", 0.0) / cu_cycles,
-                                                    "valu_busy_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cu_cycles * 4.0) if c.get("SQ_ACTIVE_INST_VALU") else None,
+                                                    "valu_busy_frac": (4.0 * c["SQ_ACTIVE_INST_VALU"] / (4.0 * cu_cycles)) if c.get("SQ_ACTIVE_INST_VALU") else None,
+                                                    "mfma_busy_frac": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu_cycles)) if c.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                                                     "note": "what binds the kernel: the texture path and the VALU, not a memory level"}
         else:
             result["roofline"]["traffic_stale"] = info
