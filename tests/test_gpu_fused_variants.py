@@ -163,3 +163,33 @@ def test_tiny_frames_leave_most_band_queues_empty(oracle, dev, n_rays):
     assert abs(int(stats[0]) - ref["samples"]) <= 8 and stats[2] == int((ref["consumed"] > 0).sum())
     assert np.max(np.abs(out["image"].reshape(-1, 3).cpu().numpy() - ref["image"])) < 5e-3
     assert np.isfinite(out["weights_sum"].cpu().numpy()).all()
+
+
+def test_fused_path_refuses_non_default_fields_and_uses_the_renderers_density_scale(dev):
+    """fused_state() packed raw pointers without checking the architecture the kernels are specialised for, and took
+    density_scale from the field while the per-op paths use the renderer's (nerf/renderer.py:64 owns the one density_scale)."""
+    import numpy as np
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    for kw in (dict(num_layers_color=2), dict(num_layers=3)):
+        odd = NGPFieldFF(bound=W.BOUND, **kw).to(dev)
+        with pytest.raises(RuntimeError, match="default field"):
+            odd.fused_state()
+    model = W.make_model(0)
+    field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(model)
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0, density_scale=0.5).to(dev).eval()
+    ren.load_density_grid(W.density_grid())
+    o, d = W.get_rays(W.orbit_pose(2), W.intrinsics(48, 48), 48, 48)
+    to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+    fused = ren.render_fused(to, td, bg_color=1)["image"]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        perop = ren.run_cuda(to, td, bg_color=1)["image"]
+    assert float((fused - perop).abs().max()) < 5e-3
+    ren1 = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0, density_scale=1.0).to(dev).eval()
+    ren1.load_density_grid(W.density_grid())
+    assert float((ren1.render_fused(to, td, bg_color=1)["image"] - fused).abs().max()) > 1e-2      # the scale does reach the kernel
+    # moving the module drops the cached half copies (module.to() replaces storage without bumping _version)
+    st0 = field.fused_state()
+    field.float()
+    assert field._fused is None and field.fused_state() is not st0
