@@ -174,6 +174,12 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
                             int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners,
                             int dtype, void* stream);
 
+/* The same forward (calc_grad_inputs = 0) writing outputs [B, L*C] directly -- what GridEncoder.forward returns after the reference's
+ * permute + reshape copy (gridencoder/grid.py:42,52).  Same values, bit for bit; D = 3 and C = 2 only. */
+int ngp_grid_encode_forward_rows(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                 uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 uint32_t gridtype, int align_corners, int dtype, void* stream);
+
 /* gridencoder.h:13 grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
  *                                       calc_grad_inputs, dy_dx, grad_inputs, gridtype, align_corners)
  * grad [L,B,C]; grad_embeddings [sO,C] PRE-ZEROED, or NULL when only grad_inputs is wanted (frozen model: skips the

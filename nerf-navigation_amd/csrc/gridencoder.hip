@@ -446,6 +446,107 @@ static int ge_forward_d(uint32_t D, uint32_t C, const float* inputs, const void*
     }
 }
 
+// ---------------------------------------------------------------------------
+// forward straight into the layout the caller wants, [B, L*C]
+//
+// The reference's kernel writes [L, B, C] (a level per blockIdx.y) and its wrapper then permutes and copies to [B, L*C] (grid.py:42,52): 41 MB read
+// and written again per call at 640 k points, 64 times per rendered frame.  Here a workgroup owns 256 samples, walks the L levels itself, parks the
+// L*C values of every sample in LDS (rows padded to an odd number of words: conflict-free column writes) and writes whole rows, coalesced.
+// Arithmetic per (sample, level): k_grid_forward's, operation for operation, so the values are the same bits.  D = 3, C = 2 (the reference's grid).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_grid_forward_rows(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                           const int* __restrict__ offsets, T* __restrict__ outputs,
+                                                           uint32_t B, uint32_t L, ge_levels lv, uint32_t gridtype, bool align_corners) {
+    constexpr uint32_t D = 3, C = 2;
+    using num = ge_num<T>;
+    using vec = ge_vec<T, C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ge_smem[];
+    vec* tile = reinterpret_cast<vec*>(ge_smem);                       // [256][L + 1] feature pairs
+    const uint32_t stride = L + 1;
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const bool live = b < B;
+    float xin[D] = {0.0f, 0.0f, 0.0f};
+    bool oob = !live;
+    if (live) {
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) { xin[d] = inputs[(uint64_t)b * D + d]; oob |= (xin[d] < 0 || xin[d] > 1); }
+    }
+    for (uint32_t level = 0; level < L; level++) {
+        vec o;
+        o.v[0] = (T)0.0f; o.v[1] = (T)0.0f;
+        if (!oob) {
+            const vec* tab = reinterpret_cast<const vec*>(grid) + (uint32_t)offsets[level];
+            const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+            const float scale = lv.scale[level];
+            const uint32_t resolution = lv.resolution[level];
+            float pos[D];
+            uint32_t pg[D];
+            #pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = xin[d] * scale + (align_corners ? 0.0f : 0.5f);
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+            }
+            vec corner[8];
+            float w[8];
+            #pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float wi = 1;
+                uint32_t pl[D];
+                #pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { wi *= 1 - pos[d]; pl[d] = pg[d]; }
+                    else { wi *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                w[idx] = wi;
+                corner[idx] = tab[ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+            }
+            float res[C] = {0.0f, 0.0f};
+            #pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                #pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float prod = num::rnd(w[idx] * (float)corner[idx].v[ch]);
+                    res[ch] = num::rnd(res[ch] + prod);
+                }
+            }
+            o.v[0] = (T)res[0]; o.v[1] = (T)res[1];
+        }
+        tile[threadIdx.x * stride + level] = o;
+    }
+    __syncthreads();
+    // rows out: consecutive lanes write consecutive feature pairs of a row, 256 / L rows per pass
+    const uint32_t rows_here = (B - blockIdx.x * 256u) < 256u ? (B - blockIdx.x * 256u) : 256u;
+    vec* out = reinterpret_cast<vec*>(outputs) + (uint64_t)blockIdx.x * 256 * L;
+    for (uint32_t i = threadIdx.x; i < rows_here * L; i += 256) {
+        const uint32_t r = i / L, c = i - r * L;
+        out[i] = tile[r * stride + c];
+    }
+}
+
+extern "C" int ngp_grid_encode_forward_rows(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                            uint32_t gridtype, int align_corners, int dtype, void* stream) {
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward_rows: null pointer");
+    NGP_REQUIRE(D == 3 && C == 2, "grid_encode_forward_rows: D must be 3 and C 2 (use grid_encode_forward + a permute otherwise)");
+    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_encode_forward_rows: L must be in 1..32");
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_forward_rows: dtype must be f32 or f16");
+    ge_levels lv;
+    ge_fill_levels(lv, L, S, H);
+    const dim3 grid_dim(ngp_div_up(B, 256)), block(256);
+    const size_t lds = 256 * (size_t)(L + 1) * 2 * (dtype == NGP_F32 ? 4 : 2);
+    if (dtype == NGP_F32)
+        hipLaunchKernelGGL(k_grid_forward_rows<float>, grid_dim, block, lds, (hipStream_t)stream, inputs, (const float*)embeddings, offsets, (float*)outputs,
+                           B, L, lv, gridtype, align_corners != 0);
+    else
+        hipLaunchKernelGGL(k_grid_forward_rows<_Float16>, grid_dim, block, lds, (hipStream_t)stream, inputs, (const _Float16*)embeddings, offsets,
+                           (_Float16*)outputs, B, L, lv, gridtype, align_corners != 0);
+    NGP_CHECK_LAUNCH("grid_encode_forward_rows");
+    return NGP_OK;
+}
+
 extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                        int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners,

@@ -23,6 +23,8 @@ RECOMPUTE_INPUT_GRAD = True
 # ... from this many points on: the recomputing kernel walks the levels of a point in one lane (that keeps the reference's
 # summation order), so a small batch (the planner's 10,000 body points) does not fill the chip and is faster with dy_dx
 RECOMPUTE_MIN_POINTS = 32768
+# True: D = 3, C = 2 forwards write [B, L*C] directly (ngp_grid_encode_forward_rows) instead of [L, B, C] + permute copy.  Same bits.
+ROWS_FORWARD = True
 
 
 # The reference converts the float32 table to half on EVERY autocast forward (grid.py:38-39: 50 MB read + 25 MB written per call, 64
@@ -63,19 +65,26 @@ class _grid_encode(Function):
         if inputs.dtype != torch.float32:
             raise RuntimeError("inputs must be a float32 tensor")
 
-        outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
         recompute = bool(calc_grad_inputs) and RECOMPUTE_INPUT_GRAD and B >= RECOMPUTE_MIN_POINTS and D in (2, 3) and C in (1, 2, 4, 8)
         if calc_grad_inputs and not recompute:
             dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype)
         else:
             dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)
 
-        _hip.check(_hip.lib().ngp_grid_encode_forward(_hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets), _hip.ptr(outputs),
-                                                      B, D, C, L, float(S), H, int(calc_grad_inputs and not recompute), _hip.ptr(dy_dx),
-                                                      gridtype, int(align_corners), _hip.dtype_code(embeddings.dtype),
-                                                      _hip.stream()), "grid_encode_forward")
-
-        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+        if ROWS_FORWARD and D == 3 and C == 2 and not (calc_grad_inputs and not recompute):
+            # the reference's kernel writes [L, B, C] and grid.py:42,52 permutes + copies to [B, L*C]; this kernel writes the rows directly
+            # (same bits): one launch and 2 x B x L x C values of traffic less per call
+            outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
+            _hip.check(_hip.lib().ngp_grid_encode_forward_rows(_hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets), _hip.ptr(outputs),
+                                                               B, D, C, L, float(S), H, gridtype, int(align_corners),
+                                                               _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_forward_rows")
+        else:
+            outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
+            _hip.check(_hip.lib().ngp_grid_encode_forward(_hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets), _hip.ptr(outputs),
+                                                          B, D, C, L, float(S), H, int(calc_grad_inputs and not recompute), _hip.ptr(dy_dx),
+                                                          gridtype, int(align_corners), _hip.dtype_code(embeddings.dtype),
+                                                          _hip.stream()), "grid_encode_forward")
+            outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype]

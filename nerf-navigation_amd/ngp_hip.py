@@ -50,6 +50,7 @@ _SIGNATURES = {
     "ngp_mark_untrained_grid": (c_int, [c_vp, c_u32, c_f32, c_f32, c_f32, c_f32, c_u32, c_u32, c_f32, c_vp, c_vp]),
     "ngp_grid_encode_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_int, c_vp,
                                         c_u32, c_int, c_int, c_vp]),
+    "ngp_grid_encode_forward_rows": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_u32, c_int, c_int, c_vp]),
     "ngp_grid_encode_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_int,
                                          c_vp, c_vp, c_u32, c_int, c_int, c_vp]),
     "ngp_sh_encode_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_int, c_vp, c_vp]),

@@ -287,3 +287,27 @@ def test_grid_input_gradient_without_dy_dx_is_bit_identical(dev, half, level_dim
     finally:
         G.RECOMPUTE_INPUT_GRAD, G.RECOMPUTE_MIN_POINTS = True, 32768
         enc.embeddings.requires_grad_(True)
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_grid_forward_rows_equals_level_major_plus_permute(dev, half):
+    """ngp_grid_encode_forward_rows writes [B, L*C] directly; the reference's route is [L, B, C] + permute + copy (grid.py:42,52).
+    Same bits for float32 and float16 tables, with out-of-range points (zero rows) and a batch that is not a multiple of 256."""
+    import gridencoder.grid as G
+    torch.manual_seed(7)
+    enc = G.GridEncoder(desired_resolution=4096).to(dev)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = torch.rand(70001, 3, device=dev) * 2.4 - 1.2
+    outs = {}
+    for rows in (True, False):
+        G.ROWS_FORWARD = rows
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=half):
+                outs[rows] = enc(x, bound=1)
+        finally:
+            G.ROWS_FORWARD = True
+    assert outs[True].shape == (70001, 32) and outs[True].dtype == (torch.float16 if half else torch.float32)
+    assert torch.equal(outs[True], outs[False])
+    outside = ((x < -1) | (x > 1)).any(dim=-1)
+    assert outside.sum() > 1000 and (outs[True][outside] == 0).all() and outs[True][~outside].abs().sum() > 0
