@@ -162,13 +162,50 @@ def bench_train(args, rank, world, dev, W, teacher):
         dist.destroy_process_group()
 
 
+def fit_model(args, dev, W, teacher):
+    """"table/MLP obtained by fitting the field with the build's own trainer for a fixed 2,000 steps, seed 0".  The teacher is the
+    hand-set model (it IS the scene); the student starts from the reference's initialisation and its own, learned, occupancy grid."""
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    from ngp.train import NGPTrainer
+    res, n_rays = 200, 4096
+    intr = W.intrinsics(res, res)
+    radius, height = W.scene_orbit(args.workload)
+    pool = []
+    for view in range(24):
+        o, d = W.get_rays(W.orbit_pose(view, 24, radius, height + 0.25 * ((view % 3) - 1)), intr, res, res)
+        to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+        pool.append((to, td, teacher.render_fused(to, td, bg_color=1, image_width=res)["image"]))
+    torch.manual_seed(0)
+    student = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
+    tr = NGPTrainer(student, lr=1e-2, iters=args.fit_steps, fp16=True)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    t0 = time.perf_counter()
+    for k in range(args.fit_steps):
+        to, td, tc = pool[k % len(pool)]
+        idx = torch.randint(0, res * res, (n_rays,), device=dev, generator=gen)
+        loss = tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=1024)
+    torch.cuda.synchronize()
+    student.eval()
+    with torch.no_grad():
+        to, td, tc = pool[1]
+        img = student.render_fused(to, td, bg_color=1, image_width=res)["image"]
+        psnr = float(-10 * torch.log10(torch.mean((img - tc) ** 2)))
+    return student, {"steps": args.fit_steps, "seconds": time.perf_counter() - t0, "final_loss": float(loss), "psnr_vs_teacher_db": psnr,
+                     "occupied_cells": int(torch.count_nonzero(student.density_grid > min(student.mean_density, 10.0)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)     # ~1 s of GPU time; runs shorter than ~50 frames scatter by +-10 %
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--cpu-res", type=int, default=144, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR")
+    ap.add_argument("--cpu-res", type=int, default=200, help="side of the frame the CPU oracle renders for cpu_baseline / PSNR (BASELINE.md 2: 200x200)")
+    ap.add_argument("--model", default="handset", choices=["handset", "trained"],
+                    help="handset = the field whose table / weights are set by hand to represent the scene (headline); trained = a fresh field fitted to "
+                         "renders of it with the package's own trainer for --fit-steps steps, seed 0 (SURVEY 8d), then rendered")
+    ap.add_argument("--fit-steps", type=int, default=2000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "per_op", "per_op_fused_field"],
                     help="fused = headline (rays resident); fused_camera = rays generated inside the frame kernel from the pose; "
@@ -214,6 +251,11 @@ def main():
 
     if args.mode == "train":
         return bench_train(args, rank, world, dev, W, ren)
+
+    fit = None
+    if args.model == "trained":
+        ren, fit = fit_model(args, dev, W, ren)                  # untimed: the bench renders the fitted model
+        model = None
 
     H = Wd = args.res
     intr = W.intrinsics(H, Wd)
@@ -370,9 +412,17 @@ def main():
         else:
             result["roofline"]["traffic_stale"] = info
 
+    if fit is not None:
+        result["config"]["model"] = "trained"
+        result["fit"] = fit
     if not args.no_cpu and world == 1:
         from oracle import ngp_oracle as O, render_oracle as R
         O.build()
+        if model is None:                                    # the fitted student: hand the oracle its parameters
+            f = ren.field
+            model = dict(embeddings=f.encoder.embeddings.detach().float().cpu().numpy(), offsets=f.encoder.offsets.cpu().numpy(),
+                         per_level_scale=float(f.encoder.per_level_scale), sigma_weights=f.sigma_net.weights.detach().float().cpu().numpy(),
+                         color_weights=f.color_net.weights.detach().float().cpu().numpy(), bound=W.BOUND)
         r = args.cpu_res
         o, d = W.get_rays(W.orbit_pose(0, n_poses, radius, height), W.intrinsics(r, r), r, r)
         bitfield = ren.density_bitfield.cpu().numpy()
@@ -383,6 +433,16 @@ def main():
         img = gpu["image"][0].cpu().numpy()
         result["psnr_vs_oracle_db"] = R.psnr(img, ref["image"])
         result["max_abs_vs_oracle"] = float(np.max(np.abs(img - ref["image"])))
+        # BASELINE config 1 ("Lego 64x64, CPU plumbing"): bound 1, one cascade, 64x64 view from the radius-3.2 orbit, timed end to end
+        m1 = W.make_model(0, bound=1.0)
+        g1 = W.density_grid(bound=1.0)
+        bf1, _ = W.bitfield_from_grid(g1)
+        o1, d1 = W.get_rays(W.orbit_pose(0, 8, 3.2, 1.2), W.intrinsics(64, 64), 64, 64)
+        t2 = time.perf_counter()
+        ref1 = R.run_cuda(lambda x, dd: R.field_forward(m1, x, dd, 1.0), o1, d1, bf1, 1.0, 1)
+        cfg1_s = time.perf_counter() - t2
+        result["cpu_config1"] = {"workload": "64x64 single view, bound 1, oracle run_cuda (BASELINE config 1), end to end", "seconds": cfg1_s,
+                                 "ray_samples": ref1["samples"], "value": ref1["samples"] / max(cfg1_s, 1e-9), "unit": "ray-samples/s"}
         result["cpu_baseline"] = {
             "value": ref["samples"] / cpu_s,
             "unit": "ray-samples/s",

@@ -20,6 +20,7 @@
 //
 // Arithmetic: float32 like the reference path, but sums are fused multiply-adds in a fixed order of their own (rocBLAS has its own):
 // results agree with the torch path to float32 rounding (tests/test_gpu_nav_native.py states the tolerances against the CPU oracle).
+#include <atomic>
 #include "ngp_sh.h"
 
 static constexpr int NV_L = 16;            // levels
@@ -601,14 +602,19 @@ extern "C" int ngp_nav_field_prepare(const ngp_nav_field_t* f, void* workspace, 
     return NGP_OK;
 }
 
-static void nav_allow_big_lds() {                                       // the run kernels use more than the default 64 KiB of dynamic LDS
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute((const void*)k_nav_density_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_nav_density_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_nav_run_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_nav_run_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
+// the kernels use slightly more than the default 64 KiB of dynamic LDS; the raised limit is a per-device function attribute
+static int nav_allow_big_lds() {
+    static std::atomic<unsigned long long> devices{0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0) return ngp_fail(NGP_ELAUNCH, "nav: no current device");
+    const unsigned long long bit = 1ull << (device & 63);
+    if (device < 64 && (devices.load(std::memory_order_acquire) & bit)) return NGP_OK;
+    const void* kernels[4] = {(const void*)k_nav_density_fwd, (const void*)k_nav_density_bwd, (const void*)k_nav_run_fwd, (const void*)k_nav_run_bwd};
+    for (const void* k : kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return ngp_fail(NGP_ELAUNCH, "nav: cannot raise the dynamic LDS limit");
+    devices.fetch_or(bit, std::memory_order_release);
+    return NGP_OK;
 }
 
 static int nav_fill(const char* who, const ngp_nav_field_t* f, const void* prepared, nav_params& P) {
@@ -655,7 +661,7 @@ extern "C" int ngp_nav_density_forward(const ngp_nav_field_t* f, const void* pre
     if (rc != NGP_OK) return rc;
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(xyz && sigma, "nav_density_forward: null pointer");
-    nav_allow_big_lds();
+    { const int rc_lds = nav_allow_big_lds(); if (rc_lds != NGP_OK) return rc_lds; }
     hipLaunchKernelGGL(k_nav_density_fwd, dim3(ngp_div_up(M, NV_BLOCK)), dim3(NV_BLOCK), sizeof(float) * (16 + NV_H * NV_BLOCK), (hipStream_t)stream, P, xyz, M, sigma, geo);
     NGP_CHECK_LAUNCH("nav_density_forward");
     return NGP_OK;
@@ -668,7 +674,7 @@ extern "C" int ngp_nav_density_backward(const ngp_nav_field_t* f, const void* pr
     if (rc != NGP_OK) return rc;
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(xyz && grad_sigma && grad_xyz, "nav_density_backward: null pointer");
-    nav_allow_big_lds();
+    { const int rc_lds = nav_allow_big_lds(); if (rc_lds != NGP_OK) return rc_lds; }
     hipLaunchKernelGGL(k_nav_density_bwd, dim3(ngp_div_up(M, NV_BLOCK)), dim3(NV_BLOCK), sizeof(float) * (16 + NV_H * NV_BLOCK), (hipStream_t)stream, P, xyz, M, grad_sigma, grad_geo, grad_xyz);
     NGP_CHECK_LAUNCH("nav_density_backward");
     return NGP_OK;
@@ -699,7 +705,7 @@ extern "C" int ngp_nav_run_forward(const ngp_nav_field_t* f, const void* prepare
     NGP_REQUIRE(image && depth && weights_sum, "nav_run_forward: null output");
     NGP_REQUIRE(!saved || saved_bytes >= ngp_nav_run_saved_bytes(N, num_steps), "nav_run_forward: `saved` is smaller than ngp_nav_run_saved_bytes(N, num_steps)");
     const size_t lds = sizeof(float) * (16 + NV_H * NV_BLOCK);
-    nav_allow_big_lds();
+    { const int rc_lds = nav_allow_big_lds(); if (rc_lds != NGP_OK) return rc_lds; }
     hipLaunchKernelGGL(k_nav_run_fwd, dim3(N), dim3(NV_BLOCK), lds, (hipStream_t)stream, P, R, image, depth, weights_sum, (uint32_t*)saved);
     NGP_CHECK_LAUNCH("nav_run_forward");
     return NGP_OK;
@@ -719,7 +725,7 @@ extern "C" int ngp_nav_run_backward(const ngp_nav_field_t* f, const void* prepar
     NGP_REQUIRE(grad_image && grad_rays_o && grad_rays_d, "nav_run_backward: null pointer");
     NGP_REQUIRE(saved && saved_bytes >= ngp_nav_run_saved_bytes(N, num_steps), "nav_run_backward: needs the `saved` buffer its forward filled");
     const size_t lds = sizeof(float) * (16 + NV_H * NV_BLOCK);
-    nav_allow_big_lds();
+    { const int rc_lds = nav_allow_big_lds(); if (rc_lds != NGP_OK) return rc_lds; }
     hipLaunchKernelGGL(k_nav_run_bwd, dim3(N), dim3(NV_BLOCK), lds, (hipStream_t)stream, P, R, grad_image, grad_depth, grad_weights_sum,
                        (const uint32_t*)saved, grad_rays_o, grad_rays_d);
     NGP_CHECK_LAUNCH("nav_run_backward");

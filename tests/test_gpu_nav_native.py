@@ -118,6 +118,27 @@ def test_graphed_native_density(model, dev):
         assert torch.equal(sa, sb) and torch.equal(a.grad, b.grad)
 
 
+def test_native_run_edge_cases(model, dev):
+    """rays that miss the box (near = far = FLT_MAX: the reference's run() produces NaN / garbage for them too) must not disturb the others
+    or fault; a batch of one ray; rays starting inside the box; no gradient requested -> nothing is saved"""
+    from ngp import nav
+    W, q, ref = model["W"], model["q"], model["ref"]
+    o, d = W.get_rays(W.orbit_pose(3), W.intrinsics(16, 16), 16, 16)
+    o = np.concatenate([o, [[5, 5, 5], [0.1, 0.2, -0.3], [0.0, 0.0, 0.0]]]).astype(np.float32)
+    d = np.concatenate([d, [[1, 0, 0], [0, 0, 1], [0.6, 0.0, 0.8]]]).astype(np.float32)       # a miss, and two rays from inside the box
+    with torch.no_grad():
+        a = q.render_fn(t(o, dev)[None], t(d, dev)[None])
+        b = ref.render_fn(t(o, dev)[None], t(d, dev)[None])
+    hit = np.ones(len(o), bool); hit[256] = False
+    assert torch.allclose(a["image"][0][hit], b["image"][0][hit], atol=2e-4) and torch.allclose(a["depth"][0][hit], b["depth"][0][hit], atol=2e-4)
+    one = q.render_fn(t(o[257:258], dev)[None], t(d[257:258], dev)[None])
+    assert torch.allclose(one["image"][0], a["image"][0][257:258], atol=1e-6)
+    ro, rd = t(o[hit], dev)[None].requires_grad_(True), t(d[hit], dev)[None].requires_grad_(True)
+    out = q.render_fn(ro, rd)
+    out["image"].sum().backward()
+    assert torch.isfinite(ro.grad).all() and torch.isfinite(rd.grad).all()
+
+
 def test_native_queries_refuse_what_they_do_not_implement(model, dev):
     from ngp import nav
     from ngp import workload as W
