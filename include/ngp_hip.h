@@ -83,6 +83,11 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                          int32_t* rays, int32_t* counter, uint32_t perturb,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Validation switch, process-wide, default 1: with dt_gamma == 0 the count pass of ngp_march_rays_train marches one WAVE per ray (64 lattice
+ * points per step, csrc/raymarching.hip: k_march_train_count_wave) instead of one lane per ray.  Same samples, counts and order either way;
+ * returns the previous setting. */
+int ngp_march_set_wave_per_ray(int enabled);
+
 /* raymarching.h:14 composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
 int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image,

@@ -6,6 +6,7 @@
 // N/256 workgroups -- >= 2500 for an 800x800 frame, enough to fill 256 CUs several times over.  The occupancy
 // bitfield (cascade * 128^3 / 8 = 0.5 MB at bound 2) is L2-resident; the kernels are bound by the divergent
 // per-ray loops, not by HBM.
+#include <atomic>
 #include "ngp_march.h"
 
 thread_local char ngp_err_buf[512] = {0};
@@ -267,6 +268,124 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// ---------------------------------------------------------------------------
+// The count pass with ONE WAVE PER RAY (dt_gamma == 0, grids whose cell index is exact: the usual case).
+//
+// One lane per ray walks ~600 dependent probes while 4,096 rays fill 64 waves of a 1,024-SIMD chip (0.88 ms per training step, all of it
+// latency).  With a constant step the points the reference can ever test form a fixed lattice t_0 = start, t_{k+1} = fl(t_k + dt), and inside
+// one binade fl(t + dt) = t + du with the same du for every t (ngp_lattice_jump, ngp_march.h): 64 consecutive lattice points are
+// t_cur + k du, exactly.  So 64 lanes evaluate 64 lattice points at once (cell, occupancy bit, the cell's exit parameter), and the wave then
+// replays the reference's control flow over them -- which points it TESTS -- run by run instead of point by point:
+//     an occupied tested point is a sample, and so is every following lattice point of the same cell (after a sample the reference steps
+//     by dt and tests again);
+//     an empty tested point p sends the reference to the first lattice point >= cell_exit(p) (raymarching.cu:392-402), evaluated here
+//     with p's own arithmetic, so that the rounding of the exit parameter decides exactly as it does there.
+// A window has ~8 runs, so the replay is ~8 uniform iterations of a ballot and a readlane.  Same samples, same order, same count as
+// k_march_train_count, bit for bit (tests/test_gpu_raymarching.py compares both with the oracle).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_args a, int* __restrict__ rays, const int* __restrict__ counter,
+                                                                     float* __restrict__ tbuf) {
+    const uint32_t* lds_coarse = rm_stage_coarse(a);
+    const uint32_t n = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    ngp_march_t m;
+    m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+    const float far = a.fars[n];
+    const float dtc = ngp_clampf(0.0f, m.dt_min, m.dt_max);            // dt(t) for dt_gamma == 0
+    float t_cur = train_t0(m, a.nears[n], n, a.perturb);
+    float* tb = tbuf + (size_t)n * a.max_steps;
+    uint32_t count = 0;
+    float t_skip = -__builtin_inff();                                  // lattice points below it are not tested (an empty cell is being left)
+    int guard = 0;
+    while (t_cur < far && count < a.max_steps && ++guard < NGP_SKIP_GUARD) {
+        // ---- the window's lattice points: t_cur + k du, exact for k <= kmax ----
+        const float t1 = t_cur + dtc;                                  // the reference's own step
+        const float du = t1 - t_cur;                                   // exact
+        if (!(du > 0.0f)) break;                                       // no progress: the reference would spin (its guard ends it)
+        int e;
+        (void)frexpf(t_cur, &e);
+        const float end = __builtin_ldexpf(1.0f, e);
+        const float err = dtc - du;
+        int kmax = 1;
+        if (t1 < end && fabsf(err) != __builtin_ldexpf(1.0f, e - 25)) {
+            const float J = floorf((end - t1) * __builtin_amdgcn_rcpf(du)) - 1.0f;     // t1 + j du < end for j <= J whatever the rounding here
+            if (J > 0.0f) kmax = 1 + (int)fminf(J, 62.0f);
+        }
+        const float tk = t_cur + (float)lane * du;                     // exact for lane <= kmax
+        const bool valid = lane <= kmax && tk < far;
+        // ---- every lane: its point's cell, occupancy and exit parameter (the arithmetic of ngp_march_t::probe) ----
+        ngp_point<ngp_march_t> r;
+        r.at(m, valid ? tk : t_cur);
+        const uint32_t mort = ngp_morton3((uint32_t)r.nx, (uint32_t)r.ny, (uint32_t)r.nz);
+        bool occ = false;
+        {
+            const uint32_t blk = mort >> 6;
+            const bool maybe = !lds_coarse || ((lds_coarse[(uint32_t)r.level * a.coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u);
+            if (maybe) {
+                const uint2 w = reinterpret_cast<const uint2*>(a.grid)[(uint32_t)r.level * m.blocks_per_level + blk];
+                occ = (((mort & 32u) ? w.y : w.x) >> (mort & 31u)) & 1u;
+            }
+        }
+        const float tt = r.cell_exit(m, valid ? tk : t_cur);
+        const uint32_t cell = ((uint32_t)r.level << 30) | mort;        // level < 4 is implied by C * H^3 <= 2^24 with H >= 16 ... see host check
+        const uint32_t prev_cell = __shfl_up(cell, 1, 64);
+        const unsigned long long valid_mask = __ballot(valid);
+        const unsigned long long occ_mask = __ballot(valid && occ);
+        const unsigned long long heads = __ballot(lane == 0 || cell != prev_cell);       // bit k: lane k starts a run of one cell
+        // ---- replay of the reference's control flow over the window ----
+        unsigned long long smask = 0ull;                               // lattice points that are samples
+        int after = -1;                                                // candidates are lanes > after
+        uint32_t room = a.max_steps - count;
+        for (int it = 0; it < 66 && room > 0; it++) {
+            const unsigned long long low = after < 0 ? 0ull : (after >= 63 ? ~0ull : ((2ull << after) - 1ull));
+            const unsigned long long cand = valid_mask & __ballot(tk >= t_skip) & ~low;
+            if (!cand) break;
+            const int j = __builtin_ctzll(cand);
+            if ((occ_mask >> j) & 1ull) {
+                // the rest of this cell's run is tested point by point and every point is a sample
+                const unsigned long long later_heads = heads & ~((j >= 63) ? ~0ull : ((2ull << j) - 1ull));
+                int run_end = later_heads ? __builtin_ctzll(later_heads) - 1 : 63;
+                const int last_valid = 63 - __builtin_clzll(valid_mask);
+                if (run_end > last_valid) run_end = last_valid;
+                if ((uint32_t)(run_end - j + 1) > room) run_end = j + (int)room - 1;
+                const unsigned long long upto = run_end >= 63 ? ~0ull : ((2ull << run_end) - 1ull);
+                const unsigned long long from = j == 0 ? ~0ull : ~((1ull << j) - 1ull);
+                smask |= upto & from;
+                room -= (uint32_t)(run_end - j + 1);
+                after = run_end;
+                t_skip = -__builtin_inff();                            // after a sample the next lattice point is tested whatever came before
+            } else {
+                t_skip = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), j));
+                after = j;                                             // "do t += dt while (t < tt)": at least one step
+            }
+        }
+        // ---- record the samples' parameters in order ----
+        if ((smask >> lane) & 1ull) tb[count + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull))] = tk;
+        count += (uint32_t)__popcll(smask);
+        // next window starts one real step behind this window's last exact point
+        const int klast = kmax < 63 ? kmax : 63;
+        t_cur = (t_cur + (float)klast * du) + dtc;
+    }
+    if (lane == 0) {
+        const uint32_t slot = (uint32_t)counter[1] + n;
+        if (slot < a.N) rays[3ull * slot + 2] = (int)count;
+    }
+}
+
+// per-64-ray totals of the counts the wave kernel left in rays[.][2] (what k_march_train_count computes with its block scan)
+__global__ __launch_bounds__(RM_BLOCK) void k_march_train_sum64(const int* __restrict__ rays, const int* __restrict__ counter, uint32_t N,
+                                                                uint32_t nblocks, uint32_t* __restrict__ block_sums) {
+    const uint32_t b = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t ray_base = (uint32_t)counter[1];
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < RM_RAY_BLOCK; k++) {
+        const uint32_t n = b * RM_RAY_BLOCK + k, slot = ray_base + n;
+        if (n < N && slot < N) total += (uint32_t)rays[3ull * slot + 2];
+    }
+    block_sums[b] = total;
+}
+
 // single workgroup: exclusive scan of the per-block totals, then bump the two counters
 __global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks,
                                                                int* __restrict__ counter, uint32_t N,
@@ -377,6 +496,10 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_fill(march_args a,
     }
 }
 
+// validation switch: 0 = always march one lane per ray (tests compare the two count passes)
+static std::atomic<int> rm_wave_march_enabled{1};
+extern "C" int ngp_march_set_wave_per_ray(int enabled) { return rm_wave_march_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
+
 static size_t rm_train_ws_base(uint32_t N) { return (sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4) + 255) & ~(size_t)255; }
 
 // block sums and bases | room for a coarse occupancy map (built per call: the bitfield changes every 16 steps)
@@ -407,7 +530,14 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
         tbuf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + ngp_march_rays_train_workspace(N));
     const size_t cbytes = rm_coarse_bytes(grid, C, H);
     if (cbytes) rm_attach_coarse(a, reinterpret_cast<unsigned char*>(workspace) + rm_train_ws_base(N), s);
-    hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, block_sums, tbuf);
+    // one wave per ray when the lattice is closed-form (constant step) and the sample parameters can be recorded; else one lane per ray
+    const bool wave_per_ray = tbuf && cbytes && dt_gamma == 0.0f && C <= 4 && rm_wave_march_enabled.load(std::memory_order_relaxed);
+    if (wave_per_ray) {
+        hipLaunchKernelGGL(k_march_train_count_wave, dim3(N), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, tbuf);
+        hipLaunchKernelGGL(k_march_train_sum64, dim3(ngp_div_up(nblocks, RM_BLOCK)), dim3(RM_BLOCK), 0, s, rays, counter, N, nblocks, block_sums);
+    } else {
+        hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, block_sums, tbuf);
+    }
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
     hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas, tbuf ? 1 : 0);
     if (tbuf) hipLaunchKernelGGL(k_march_train_fill, dim3(N), dim3(RM_RAY_BLOCK), 0, s, a, rays, bases, tbuf, xyzs, dirs, deltas);

@@ -197,6 +197,45 @@ def test_march_rays_train_bit_exact(oracle, dev, scene, perturb, mode):
         assert (r_r[:, 1] + r_r[:, 2] >= x_r.shape[0]).any(), "test must include dropped rays"
 
 
+@pytest.mark.parametrize("max_steps", [1024, 24])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_wave_per_ray_count_pass_equals_lane_per_ray(oracle, dev, perturb, max_steps):
+    """the count pass with one wave per ray (k_march_train_count_wave: 64 lattice points per step, the reference's control flow replayed run by
+    run) against the one-lane-per-ray pass and against the oracle: counts, order and positions bit for bit -- 4,096 camera rays through the S-ring
+    grid plus axis-parallel and missing rays, with and without jitter, and with a max_steps small enough that the cap cuts rays short"""
+    import ngp_hip
+    import raymarching
+    from ngp import workload as W
+    from _util import camera_rays
+    bf, _ = W.bitfield_from_grid(W.density_grid())
+    if max_steps == 24:
+        bf = np.full_like(bf, 0xFF)                                     # everything occupied: every lattice point is a sample, long rays hit the cap
+    o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(64, 64), 64, 64)
+    eo, ed = camera_rays(4, radius=3.0, seed=3)
+    o, d = np.concatenate([o, eo[-4:]]), np.concatenate([d, ed[-4:]])
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    c_ref = np.zeros(2, np.int32)
+    x_r, _, l_r, r_r = oracle.march_rays_train(o, d, 2.0, bf, 2, 128, nears, fars, c_ref, -1, perturb, 128, False, 0.0, max_steps)
+    out = {}
+    for wave in (1, 0):
+        ngp_hip.lib().ngp_march_set_wave_per_ray(wave)
+        try:
+            cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+            out[wave] = raymarching.march_rays_train(t(o, dev), t(d, dev), 2.0, t(bf, dev), 2, 128, t(nears, dev), t(fars, dev), cnt, -1, perturb, 128,
+                                                     False, 0.0, max_steps) + (cnt,)
+        finally:
+            ngp_hip.lib().ngp_march_set_wave_per_ray(1)
+    for k in range(5):
+        assert torch.equal(out[1][k], out[0][k]), k
+    assert_same_bits(out[1][4], c_ref, "counter")
+    assert_same_bits(out[1][3], r_r, "rays")
+    assert_same_bits(out[1][0], x_r, "xyzs")
+    assert_same_bits(out[1][2], l_r, "deltas")
+    if max_steps == 24:
+        assert (r_r[:, 2] == max_steps).sum() > 100                       # the cap really cuts rays short
+
+
 def test_march_rays_train_matches_iterated_march_rays(oracle, scene):
     """SURVEY 8(c) relation 8 (oracle self-consistency, CPU only but kept beside its GPU siblings): marching to
     completion emits the same samples per ray as march_rays_train(force_all_rays, perturb=False)."""
