@@ -163,19 +163,17 @@ struct march_args {
     uint32_t coarse_words = 0;         // 32-bit words per cascade level (H^3 / 64 / 32)
 };
 
-// coarse[w] bit i = any cell of Morton block 32 w + i (64 cells = one aligned 64-bit word of the bitfield) is occupied
+// coarse bit b = any cell of Morton block b (64 cells = one aligned 64-bit word of the bitfield) is occupied.  One lane per block word, the
+// wave's ballot is 64 coarse bits (two words): 65,536 lanes for a bound-2 grid instead of 2,048 lanes reading 256 bytes each (8 us -> ~2 us)
 __global__ __launch_bounds__(RM_BLOCK) void k_rm_build_coarse(const uint8_t* __restrict__ bitfield, uint32_t n_blocks_total,
                                                               uint32_t* __restrict__ coarse) {
-    const uint32_t w = blockIdx.x * RM_BLOCK + threadIdx.x;
-    if (w * 32 >= n_blocks_total) return;
-    const uint64_t* b64 = reinterpret_cast<const uint64_t*>(bitfield);
-    uint32_t bits = 0;
-    #pragma unroll 8
-    for (uint32_t i = 0; i < 32; i++) {
-        const uint32_t blk = w * 32 + i;
-        if (blk < n_blocks_total && b64[blk] != 0ull) bits |= 1u << i;
+    const uint32_t blk = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const bool any = blk < n_blocks_total && reinterpret_cast<const uint64_t*>(bitfield)[blk] != 0ull;
+    const unsigned long long bits = __ballot(any);
+    if ((threadIdx.x & 63u) == 0 && blk < n_blocks_total) {             // n_blocks_total is a multiple of 64 (H >= 16)
+        coarse[blk >> 5] = (uint32_t)bits;
+        coarse[(blk >> 5) + 1] = (uint32_t)(bits >> 32);
     }
-    coarse[w] = bits;
 }
 
 static constexpr size_t RM_COARSE_MAX = 48 * 1024;                     // largest map the march kernels stage in LDS (H = 128: 4 KiB per cascade)
@@ -192,17 +190,18 @@ static size_t rm_coarse_bytes(const uint8_t* grid, uint32_t C, uint32_t H) {
 // builds the map into `dst` (device) and points the march arguments at it
 static void rm_attach_coarse(march_args& a, void* dst, hipStream_t s) {
     const uint32_t n_blocks_total = a.C * (a.H * a.H * a.H / 64);
-    hipLaunchKernelGGL(k_rm_build_coarse, dim3(ngp_div_up(n_blocks_total / 32, RM_BLOCK)), dim3(RM_BLOCK), 0, s, a.grid, n_blocks_total, (uint32_t*)dst);
+    hipLaunchKernelGGL(k_rm_build_coarse, dim3(ngp_div_up(n_blocks_total, RM_BLOCK)), dim3(RM_BLOCK), 0, s, a.grid, n_blocks_total, (uint32_t*)dst);
     a.coarse = (const uint32_t*)dst;
     a.coarse_words = a.H * a.H * a.H / 64 / 32;
 }
 
 // every thread of a RM_RAY_BLOCK workgroup calls this before marching: copies the map into dynamic LDS (or returns nullptr without one)
+template <uint32_t BLOCK = RM_RAY_BLOCK>
 __device__ __forceinline__ const uint32_t* rm_stage_coarse(const march_args& a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t rm_lds_coarse[];
     if (!a.coarse) return nullptr;
     const uint32_t nw = a.C * a.coarse_words;
-    for (uint32_t i = threadIdx.x * 4; i < nw; i += RM_RAY_BLOCK * 4)
+    for (uint32_t i = threadIdx.x * 4; i < nw; i += BLOCK * 4)
         *reinterpret_cast<uint4*>(rm_lds_coarse + i) = *reinterpret_cast<const uint4*>(a.coarse + i);
     __syncthreads();
     return rm_lds_coarse;
@@ -674,17 +673,19 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
 
 // FILL: the kernel also writes the zeros the reference gets from torch.zeros (raymarching.py:327-329): the slots a ray does not
 // reach (zero delta = terminated, raymarching.cu:867) and the alignment rows [n_alive * n_step, M); the buffers need no pre-zeroing.
-template <bool FILL>
-__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+// BLOCK: 64 threads when few rays are alive (their waves spread over 4x as many CUs), 256 when the launch fills the chip anyway (a quarter of
+// the workgroups stage the coarse map: 80 MB -> 20 MB of L2 reads per 640 k-ray launch)
+template <bool FILL, uint32_t BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
                                                          const float* __restrict__ rays_t, march_args a,
                                                          float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
     // reference: raymarching.cu:707-814
-    const uint32_t* lds_coarse = rm_stage_coarse(a);
-    const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
+    const uint32_t* lds_coarse = rm_stage_coarse<BLOCK>(a);
+    const uint32_t n = blockIdx.x * BLOCK + threadIdx.x;
     if (FILL) {
         // a.M rows in all; rows past the last ray's slots are spread over the launch's lanes
         const uint64_t used = (uint64_t)n_alive * n_step;
-        for (uint64_t r = used + n; r < a.M; r += (uint64_t)gridDim.x * RM_RAY_BLOCK) {
+        for (uint64_t r = used + n; r < a.M; r += (uint64_t)gridDim.x * BLOCK) {
             xyzs[3 * r] = 0.f; xyzs[3 * r + 1] = 0.f; xyzs[3 * r + 2] = 0.f;
             dirs[3 * r] = 0.f; dirs[3 * r + 1] = 0.f; dirs[3 * r + 2] = 0.f;
             deltas[2 * r] = 0.f; deltas[2 * r + 1] = 0.f;
@@ -771,14 +772,19 @@ static int march_rays_launch(bool fill, uint32_t M, uint32_t n_alive, uint32_t n
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays: bad C/H/max_steps");
     NGP_REQUIRE(!fill || (uint64_t)M >= (uint64_t)n_alive * n_step, "march_rays: M is smaller than n_alive * n_step");
     march_args a{rays_o, rays_d, grid, nears, fars, bound, dt_gamma, max_steps, 0u, C, H, M, perturb};
-    const dim3 grid_dim(ngp_div_up(n_alive ? n_alive : 1, RM_RAY_BLOCK)), block(RM_RAY_BLOCK);
     // the coarse map pays when rays cross empty space; it is rebuilt on every call (2 us: the bitfield may have changed, and a cache
     // keyed on a pointer could go stale silently)
     const size_t cbytes = (workspace && n_alive) ? rm_coarse_bytes(grid, C, H) : 0;
     const size_t lds = (cbytes && workspace_bytes >= cbytes) ? cbytes : 0;
     if (lds) rm_attach_coarse(a, workspace, (hipStream_t)stream);
-    if (fill) hipLaunchKernelGGL(k_march_rays<true>, grid_dim, block, lds, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
-    else hipLaunchKernelGGL(k_march_rays<false>, grid_dim, block, lds, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    const bool big = n_alive >= 65536u;
+    const uint32_t bs = big ? RM_BLOCK : RM_RAY_BLOCK;
+    const dim3 grid_dim(ngp_div_up(n_alive ? n_alive : 1, bs)), block(bs);
+    hipStream_t st = (hipStream_t)stream;
+    if (fill && big) hipLaunchKernelGGL((k_march_rays<true, RM_BLOCK>), grid_dim, block, lds, st, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    else if (fill) hipLaunchKernelGGL((k_march_rays<true, RM_RAY_BLOCK>), grid_dim, block, lds, st, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    else if (big) hipLaunchKernelGGL((k_march_rays<false, RM_BLOCK>), grid_dim, block, lds, st, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
+    else hipLaunchKernelGGL((k_march_rays<false, RM_RAY_BLOCK>), grid_dim, block, lds, st, n_alive, n_step, rays_alive, rays_t, a, xyzs, dirs, deltas);
     NGP_CHECK_LAUNCH("march_rays");
     return NGP_OK;
 }

@@ -217,10 +217,11 @@ class _march_rays(Function):
         deltas = torch.empty(M, 2, dtype=rays_o.dtype, device=rays_o.device)
         L = _hip.lib()
         ws = _hip.workspace(L.ngp_march_rays_workspace(C, H), rays_o.device)     # coarse occupancy map, rebuilt by the call
-        _hip.check(L.ngp_march_rays_fill(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t), _hip.ptr(rays_o),
-                                         _hip.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _hip.ptr(density_bitfield),
-                                         _hip.ptr(near), _hip.ptr(far), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas),
-                                         M, int(perturb), _hip.ptr(ws), ws.numel(), _hip.stream()), "march_rays")
+        with _hip.timed("march_rays"):
+            _hip.check(L.ngp_march_rays_fill(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t), _hip.ptr(rays_o),
+                                             _hip.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _hip.ptr(density_bitfield),
+                                             _hip.ptr(near), _hip.ptr(far), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas),
+                                             M, int(perturb), _hip.ptr(ws), ws.numel(), _hip.stream()), "march_rays")
         return xyzs, dirs, deltas
 
 
