@@ -186,7 +186,7 @@ class NGPField(nn.Module):
     """nerf/network.py: the same field with nn.Linear(bias=False) layers (32->64->16 ; 31->64->64->3)."""
 
     def __init__(self, bound=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
-                 density_scale=1):
+                 density_scale=1, bg_radius=-1, num_layers_bg=2, hidden_dim_bg=64):
         super().__init__()
         self.bound = bound
         self.density_scale = density_scale
@@ -197,6 +197,14 @@ class NGPField(nn.Module):
         self.encoder_dir, self.in_dim_dir = get_encoder("sphere_harmonics")
         dims = [self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3]
         self.color_net = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers_color)])
+        # background model on a sphere of radius bg_radius (nerf/network.py:69-92): a small 2-D hash grid of the sphere coordinates
+        # ++ SH of the direction -> MLP -> sigmoid.  Only the default network has one (main_nerf.py:73: "not implemented for --ff").
+        self.bg_radius = bg_radius
+        self.bg_net = None
+        if bg_radius > 0:
+            self.encoder_bg, self.in_dim_bg = get_encoder("hashgrid", input_dim=2, num_levels=4, log2_hashmap_size=19, desired_resolution=2048)
+            dims = [self.in_dim_bg + self.in_dim_dir] + [hidden_dim_bg] * (num_layers_bg - 1) + [3]
+            self.bg_net = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers_bg)])
 
     @staticmethod
     def _mlp(layers, h):
@@ -232,6 +240,14 @@ class NGPField(nn.Module):
             return rgbs.index_copy(0, rows, h.to(rgbs.dtype))
         return h
 
+    def background(self, x, d):
+        """nerf/network.py:145-161: x [N,2] sphere coordinates in [-1,1] (raymarching.sph_from_ray), d [N,3] -> rgb [N,3]"""
+        h = torch.cat([self.encoder_dir(d), self.encoder_bg(x)], dim=-1)
+        return torch.sigmoid(self._mlp(self.bg_net, h))
+
     def get_params(self, lr):
-        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
-                {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]
+        params = [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                  {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]
+        if self.bg_radius > 0:
+            params += [{"params": self.encoder_bg.parameters(), "lr": lr}, {"params": self.bg_net.parameters(), "lr": lr}]
+        return params

@@ -41,7 +41,7 @@ def sample_pdf(bins, weights, n_samples, det=False, generator=None):
 
 
 class NGPRenderer(nn.Module):
-    def __init__(self, field, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.01, grid_size=128):
+    def __init__(self, field, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.01, grid_size=128, bg_radius=-1):
         super().__init__()
         self._mean_host, self._mean_dev = 0, None
         self.field = field
@@ -51,7 +51,9 @@ class NGPRenderer(nn.Module):
         self.density_scale = density_scale
         self.min_near = min_near
         self.density_thresh = density_thresh
-        self.bg_radius = -1
+        self.bg_radius = bg_radius                          # > 0: the field's background model colours what the rays do not hit (:61,233-236)
+        if bg_radius > 0 and getattr(field, "bg_net", None) is None:
+            raise ValueError("bg_radius > 0 needs a field with a background model (NGPField(bg_radius=...)); the reference has none for --ff")
         self.cuda_ray = cuda_ray
         aabb = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
         self.register_buffer("aabb_train", aabb)
@@ -77,6 +79,16 @@ class NGPRenderer(nn.Module):
     def color(self, x, d, mask=None, **kwargs):
         return self.field.color(x, d, mask=mask, **kwargs)
 
+    def background(self, x, d):
+        return self.field.background(x, d)
+
+    def _bg_color(self, rays_o, rays_d, bg_color):
+        """nerf/renderer.py:233-238 / :273-278: the background model's colour per ray when there is one, else bg_color, else white"""
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            return self.background(sph, rays_d)
+        return 1 if bg_color is None else bg_color
+
     def reset_extra_state(self):
         if not self.cuda_ray:
             return
@@ -98,8 +110,7 @@ class NGPRenderer(nn.Module):
         N, device = rays_o.shape[0], rays_o.device
         with torch.no_grad():
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self._aabb(), self.min_near)
-        if bg_color is None:
-            bg_color = 1
+        bg_color = self._bg_color(rays_o, rays_d, bg_color)
         results = {}
 
         if self.training:
@@ -270,8 +281,7 @@ class NGPRenderer(nn.Module):
         ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
         depth = torch.sum(weights * ori_z_vals, dim=-1)
         image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
-        if bg_color is None:
-            bg_color = 1
+        bg_color = self._bg_color(rays_o, rays_d, bg_color)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
 

@@ -192,6 +192,15 @@ class DefaultField:
             return rgbs
         return h
 
+    def background(self, sph, d, embeddings_bg, offsets_bg, per_level_scale_bg, bg_weights):
+        """NeRFNetwork.background (nerf/network.py:145-161): 2-D hash grid (4 levels, base 16) of the sphere coordinates in [-1,1] ++ SH16(d)
+        -> bias-free Linear layers -> sigmoid.  The 2-D grid goes through the C restatement (no gradient: used for images only)."""
+        x01 = ((sph.numpy().astype(np.float32) + np.float32(1)) / np.float32(2)).astype(np.float32)
+        feats, _ = O.grid_encode_forward(x01, np.asarray(embeddings_bg, np.float32), np.asarray(offsets_bg, np.int32), per_level_scale_bg, 16, False, 0, False)
+        enc = torch.from_numpy(np.ascontiguousarray(feats.transpose(1, 0, 2).reshape(x01.shape[0], -1))).to(self.dtype)
+        h = torch.cat([sh_encode(d.to(self.dtype)), enc], dim=-1)
+        return torch.sigmoid(self._mlp([torch.as_tensor(np.asarray(w), dtype=self.dtype) for w in bg_weights], h))
+
     def forward(self, x, d):                                            # network.py:95-123
         out = self.density(x)
         return out["sigma"], self.color(x, d, geo_feat=out["geo_feat"])

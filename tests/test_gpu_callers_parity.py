@@ -203,3 +203,45 @@ def test_training_step_ffmlp_autocast_against_oracle(dev):
         assert rel(g, wg) < 3e-2, k
     ge, go = field.encoder.embeddings.grad.float().cpu().numpy() / scale, orc.embeddings.grad.numpy()
     assert rel(ge, go) < 5e-2
+
+
+def test_background_model_against_oracle(oracle, dev):
+    """bg_radius > 0 (nerf/network.py:69-92,145-161; nerf/renderer.py:233-238,273-278): the background colour of each ray comes from a 2-D hash
+    grid over the sphere coordinates (sph_from_ray) and the direction's SH; both renderers mix it in where the rays hit nothing.
+    sph_from_ray 2e-6 (two libms), colours 1e-5, images 2e-4."""
+    from ngp import workload as W
+    from ngp.field import NGPField
+    from ngp.render import NGPRenderer
+    from oracle import callers_oracle as CO
+    torch.manual_seed(9)
+    field = NGPField(bound=W.BOUND, bg_radius=3.0).to(dev)
+    with torch.no_grad():
+        field.encoder.embeddings.uniform_(-0.5, 0.5)
+        field.encoder_bg.embeddings.uniform_(-1.0, 1.0)
+    assert len(field.get_params(1e-2)) == 6
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=False, bg_radius=3.0).to(dev).eval()
+    o, d = W.get_rays(W.orbit_pose(2), W.intrinsics(16, 16), 16, 16)
+    to, td = t(o, dev), t(d, dev)
+    import raymarching
+    sph = raymarching.sph_from_ray(to, td, 3.0)
+    sph_ref = oracle.sph_from_ray(o, d, 3.0)
+    assert np.max(np.abs(sph.cpu().numpy() - sph_ref)) < 2e-6
+    orc = oracle_field(field)
+    bgw = [l.weight.detach().cpu().numpy() for l in field.bg_net]
+    bg_ref = orc.background(torch.from_numpy(sph_ref), torch.from_numpy(d), field.encoder_bg.embeddings.detach().cpu().numpy(),
+                            field.encoder_bg.offsets.cpu().numpy(), float(field.encoder_bg.per_level_scale), bgw)
+    with torch.no_grad():
+        bg = field.background(sph, td)
+        out = ren.run(to[None], td[None], num_steps=64, upsample_steps=0)
+    assert np.max(np.abs(bg.cpu().numpy() - bg_ref.numpy())) < 1e-5
+    ref = CO.run(orc, torch.from_numpy(o), torch.from_numpy(d), W.BOUND, num_steps=64, upsample_steps=0, bg_color=bg_ref)
+    assert np.max(np.abs(out["image"][0].cpu().numpy() - ref["image"].detach().numpy())) < 2e-4
+    # the occupancy-grid renderer takes the same route (nerf/renderer.py:273-278)
+    ren2 = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, bg_radius=3.0, density_thresh=10.0).to(dev).eval()
+    ren2.load_density_grid(W.density_grid())
+    with torch.no_grad():
+        img = ren2.run_cuda(to[None], td[None])["image"][0]
+    assert torch.isfinite(img).all()
+    with pytest.raises(ValueError):
+        from ngp.field import NGPFieldFF
+        NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, bg_radius=3.0)
