@@ -282,21 +282,19 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
 // A window has ~8 runs, so the replay is ~8 uniform iterations of a ballot and a readlane.  Same samples, same order, same count as
 // k_march_train_count, bit for bit (tests/test_gpu_raymarching.py compares both with the oracle).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_args a, int* __restrict__ rays, const int* __restrict__ counter,
-                                                                     float* __restrict__ tbuf) {
-    const uint32_t* lds_coarse = rm_stage_coarse(a);
-    const uint32_t n = blockIdx.x;
-    const int lane = (int)threadIdx.x;
-    ngp_march_t m;
-    m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
-    const float far = a.fars[n];
+// The window march shared by the wave-per-ray kernels: from lattice point t_start, find up to max_new samples of ONE ray (all 64 lanes hold
+// the same ray in `m`) and hand each window's samples to emit(found_so_far, smask, tk): smask = the lanes whose lattice point tk is a sample,
+// in order (du = the lattice spacing of that window).  Returns the number of samples found.  Requires dt_gamma == 0 and an exact grid (m.blocks_per_level != 0).
+template <class Emit>
+__device__ __forceinline__ uint32_t rm_wave_march(const ngp_march_t& m, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
+                                                  float t_start, float far, uint32_t max_new, Emit&& emit) {
+    const int lane = (int)(threadIdx.x & 63u);
     const float dtc = ngp_clampf(0.0f, m.dt_min, m.dt_max);            // dt(t) for dt_gamma == 0
-    float t_cur = train_t0(m, a.nears[n], n, a.perturb);
-    float* tb = tbuf + (size_t)n * a.max_steps;
+    float t_cur = t_start;
     uint32_t count = 0;
     float t_skip = -__builtin_inff();                                  // lattice points below it are not tested (an empty cell is being left)
     int guard = 0;
-    while (t_cur < far && count < a.max_steps && ++guard < NGP_SKIP_GUARD) {
+    while (t_cur < far && count < max_new && ++guard < NGP_SKIP_GUARD) {
         // ---- the window's lattice points: t_cur + k du, exact for k <= kmax ----
         const float t1 = t_cur + dtc;                                  // the reference's own step
         const float du = t1 - t_cur;                                   // exact
@@ -319,14 +317,14 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_a
         bool occ = false;
         {
             const uint32_t blk = mort >> 6;
-            const bool maybe = !lds_coarse || ((lds_coarse[(uint32_t)r.level * a.coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u);
+            const bool maybe = !lds_coarse || ((lds_coarse[(uint32_t)r.level * coarse_words + (blk >> 5)] >> (blk & 31u)) & 1u);
             if (maybe) {
-                const uint2 w = reinterpret_cast<const uint2*>(a.grid)[(uint32_t)r.level * m.blocks_per_level + blk];
+                const uint2 w = reinterpret_cast<const uint2*>(m.grid)[(uint32_t)r.level * m.blocks_per_level + blk];
                 occ = (((mort & 32u) ? w.y : w.x) >> (mort & 31u)) & 1u;
             }
         }
         const float tt = r.cell_exit(m, valid ? tk : t_cur);
-        const uint32_t cell = ((uint32_t)r.level << 30) | mort;        // level < 4 is implied by C * H^3 <= 2^24 with H >= 16 ... see host check
+        const uint32_t cell = ((uint32_t)r.level << 30) | mort;        // level < 4: the host uses these kernels for C <= 4 only
         const uint32_t prev_cell = __shfl_up(cell, 1, 64);
         const unsigned long long valid_mask = __ballot(valid);
         const unsigned long long occ_mask = __ballot(valid && occ);
@@ -334,7 +332,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_a
         // ---- replay of the reference's control flow over the window ----
         unsigned long long smask = 0ull;                               // lattice points that are samples
         int after = -1;                                                // candidates are lanes > after
-        uint32_t room = a.max_steps - count;
+        uint32_t room = max_new - count;
         for (int it = 0; it < 66 && room > 0; it++) {
             const unsigned long long low = after < 0 ? 0ull : (after >= 63 ? ~0ull : ((2ull << after) - 1ull));
             const unsigned long long cand = valid_mask & __ballot(tk >= t_skip) & ~low;
@@ -358,13 +356,27 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_a
                 after = j;                                             // "do t += dt while (t < tt)": at least one step
             }
         }
-        // ---- record the samples' parameters in order ----
-        if ((smask >> lane) & 1ull) tb[count + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull))] = tk;
+        if (smask) emit(count, smask, tk, du);
         count += (uint32_t)__popcll(smask);
         // next window starts one real step behind this window's last exact point
         const int klast = kmax < 63 ? kmax : 63;
         t_cur = (t_cur + (float)klast * du) + dtc;
     }
+    return count;
+}
+
+__global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_args a, int* __restrict__ rays, const int* __restrict__ counter,
+                                                                     float* __restrict__ tbuf) {
+    const uint32_t* lds_coarse = rm_stage_coarse(a);
+    const uint32_t n = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    ngp_march_t m;
+    m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
+    float* tb = tbuf + (size_t)n * a.max_steps;
+    const uint32_t count = rm_wave_march(m, lds_coarse, a.coarse_words, train_t0(m, a.nears[n], n, a.perturb), a.fars[n], a.max_steps,
+                                         [&](uint32_t found, unsigned long long smask, float tk, float) {
+        if ((smask >> lane) & 1ull) tb[found + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull))] = tk;    // the samples' parameters, in order
+    });
     if (lane == 0) {
         const uint32_t slot = (uint32_t)counter[1] + n;
         if (slot < a.N) rays[3ull * slot + 2] = (int)count;

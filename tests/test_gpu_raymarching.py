@@ -307,3 +307,28 @@ def test_march_to_completion_on_other_grids(oracle, dev, bound, cas, grid_h, dt_
     assert_same_bits(rays, r_ref, "rays")
     assert_same_bits(l[:total], l_ref[:total], "deltas")
     assert_same_bits(x[:total], x_ref[:total], "xyzs")
+
+
+@pytest.mark.parametrize("perturb", [0, 5])
+@pytest.mark.parametrize("n_step", [16, 200])
+@pytest.mark.parametrize("bound,cas,grid_h", [(1.0, 1, 128), (2.0, 2, 128), (4.0, 3, 64), (1.5, 2, 128)])
+def test_march_rays_many_slots_on_sparse_grids_bit_exact(oracle, dev, bound, cas, grid_h, n_step, perturb):
+    """march_rays with many slots per ray on sparse scenes (long empty stretches between samples, rays that run out at far before
+    their slots are used, resumed rays): positions, directions and both deltas bit-exact against the oracle's cell-by-cell march."""
+    import raymarching
+    bf, _ = blob_bitfield(oracle, cas, grid_h, seed=11, n_blobs=9, bound=bound)
+    o, d = camera_rays(48, radius=1.6 * bound, seed=4)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    N = o.shape[0]
+    alive = np.random.default_rng(2).permutation(N)[: N - 11].astype(np.int32)
+    rays_t = nears.copy()
+    rays_t[::4] += 0.21 * bound
+    x_ref, d_ref, l_ref = oracle.march_rays(alive.size, n_step, alive, rays_t, o, d, bound, bf, cas, grid_h, nears, fars, 128, perturb, 0.0, 1024)
+    x, dd, l = raymarching.march_rays(alive.size, n_step, t(alive, dev), t(rays_t, dev), t(o, dev), t(d, dev), bound, t(bf, dev), cas, grid_h,
+                                      t(nears, dev), t(fars, dev), 128, perturb, 0.0, 1024)
+    per_ray = (l_ref[: alive.size * n_step, 0] > 0).reshape(alive.size, n_step).sum(1)
+    assert (per_ray > 6).sum() > 200 and ((per_ray == n_step).any() if n_step == 16 else ((per_ray > 64) & (per_ray < n_step)).any())
+    assert_same_bits(l, l_ref, "deltas")
+    assert_same_bits(x, x_ref, "xyzs")
+    assert_same_bits(dd, d_ref, "dirs")
