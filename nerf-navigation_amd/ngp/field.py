@@ -59,7 +59,22 @@ def get_encoder(encoding, input_dim=3, degree=4, num_levels=16, level_dim=2, bas
     return enc, enc.output_dim
 
 
-class NGPFieldFF(nn.Module):
+class _ParamEpoch:
+    """Cached derived copies of the parameters (half table, packed weights, the nav kernels' transposes) are keyed on the tensors'
+    `_version` counters AND on this epoch.  Not every in-place update bumps `_version` (torch's fused Adam updates parameters without
+    it), but every optimiser step follows a forward that is differentiated with respect to the parameters -- and that forward advances
+    the epoch, so a later frozen-model call rebuilds its copies.  `mark_updated()` is for callers that write parameters by other means."""
+    _param_epoch = 0
+
+    def _training_forward(self):
+        if torch.is_grad_enabled() and self.encoder.embeddings.requires_grad:
+            self._param_epoch += 1
+
+    def mark_updated(self):
+        self._param_epoch += 1
+
+
+class NGPFieldFF(_ParamEpoch, nn.Module):
     """nerf/network_ff.py: density net FFMLP(32,16,64,num_layers=2), colour net FFMLP(32,3,64,num_layers=3)."""
 
     def __init__(self, bound=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
@@ -76,6 +91,7 @@ class NGPFieldFF(nn.Module):
         self._fused = None
 
     def forward(self, x, d):
+        self._training_forward()
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])
@@ -85,6 +101,7 @@ class NGPFieldFF(nn.Module):
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
+        self._training_forward()
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
@@ -100,6 +117,7 @@ class NGPFieldFF(nn.Module):
         return torch.cat([d, geo_feat, p], dim=-1)
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        self._training_forward()
         if mask is not None:
             # network.py:139-146 gathers with `t[mask]` and scatters with `rgbs[mask] = h`; the row indices of a boolean mask
             # are unique, so index_select / index_copy give the same values and the same gradients without autograd's
@@ -154,7 +172,7 @@ class NGPFieldFF(nn.Module):
         self._check_fused_shape()
         scale = float(self.density_scale if density_scale is None else density_scale)
         emb_p = self.encoder.embeddings
-        key = (emb_p._version, self.sigma_net.weights._version, self.color_net.weights._version, emb_p.data_ptr(), str(emb_p.device),
+        key = (self._param_epoch, emb_p._version, self.sigma_net.weights._version, self.color_net.weights._version, emb_p.data_ptr(), str(emb_p.device),
                self.sigma_net.weights.data_ptr(), self.color_net.weights.data_ptr(), self.encoder.offsets.data_ptr(), float(self.bound))
         if self._fused is None or self._fused["key"] != key:
             emb = emb_p.detach().to(torch.half).contiguous()
@@ -182,7 +200,7 @@ class NGPFieldFF(nn.Module):
         return sig, rgb
 
 
-class NGPField(nn.Module):
+class NGPField(_ParamEpoch, nn.Module):
     """nerf/network.py: the same field with nn.Linear(bias=False) layers (32->64->16 ; 31->64->64->3)."""
 
     def __init__(self, bound=1, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
@@ -215,6 +233,7 @@ class NGPField(nn.Module):
         return h
 
     def forward(self, x, d):
+        self._training_forward()
         h = self._mlp(self.sigma_net, self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
@@ -222,10 +241,12 @@ class NGPField(nn.Module):
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
+        self._training_forward()
         h = self._mlp(self.sigma_net, self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        self._training_forward()
         if mask is not None:
             # network.py:139-146 gathers with `t[mask]` and scatters with `rgbs[mask] = h`; the row indices of a boolean mask
             # are unique, so index_select / index_copy give the same values and the same gradients without autograd's
@@ -242,6 +263,7 @@ class NGPField(nn.Module):
 
     def background(self, x, d):
         """nerf/network.py:145-161: x [N,2] sphere coordinates in [-1,1] (raymarching.sph_from_ray), d [N,3] -> rgb [N,3]"""
+        self._training_forward()
         h = torch.cat([self.encoder_dir(d), self.encoder_bg(x)], dim=-1)
         return torch.sigmoid(self._mlp(self.bg_net, h))
 

@@ -195,7 +195,7 @@ class _NativeField:
         """(ngp_nav_field_t, prepared-weights tensor); the transposes are redone only when a parameter changed"""
         _hip, ct = self._hip, self._ct
         ps = self._params()
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (float(self.field.bound), float(self.renderer.density_scale))
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (float(self.field.bound), float(self.renderer.density_scale), getattr(self.field, "_param_epoch", 0))
         if key != self._key:
             dev = ps[0].device
             for p in ps:

@@ -57,15 +57,20 @@ class GradExchange:
 
 
 class NGPTrainer:
-    def __init__(self, renderer, lr=1e-2, iters=30000, fp16=True, update_extra_interval=16, seed=0):
+    def __init__(self, renderer, lr=1e-2, iters=30000, fp16=True, update_extra_interval=16, seed=0, fused_adam=None):
         self.ren = renderer
         self.fp16 = fp16
         self.iters = iters
         self.update_extra_interval = update_extra_interval
-        self.opt = torch.optim.Adam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
-        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         # the device type comes from the model so that the 2-rank CPU rehearsal (tests/test_distributed_cpu.py, gloo) runs the very same step
         self.device_type = next(renderer.parameters()).device.type
+        # Same update rule as the reference's Adam; on the GPU the fused implementation (one launch per parameter group instead of ~20
+        # foreach launches) takes the GradScaler's found-inf flag ON THE DEVICE, so `scaler.step` no longer reads it back: the host is
+        # not stalled once per step and can queue the next step's launches behind the running one.
+        if fused_adam is None:
+            fused_adam = self.device_type == "cuda"
+        self.opt = torch.optim.Adam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=bool(fused_adam))
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler(self.device_type, enabled=fp16)
         self.exchange = GradExchange(list(renderer.field.parameters()))
         self.global_step = 0
@@ -86,6 +91,8 @@ class NGPTrainer:
         self.exchange()                              # gradients are still scaled; the scale is identical on every rank
         self.scaler.step(self.opt)
         self.scaler.update()
+        if hasattr(ren.field, "mark_updated"):
+            ren.field.mark_updated()                 # parameters changed (fused Adam does not say so through `_version`)
         self.sched.step()
         self.global_step += 1
         return loss.detach()

@@ -199,3 +199,7 @@ def test_trainer_fits_the_scene(scene, dev):
     p1 = psnr()
     assert torch.isfinite(loss) and student.mean_count > 0 and student.iter_density == 10
     assert p1 > p0 + 3.0 and p1 > 15.0, (p0, p1)
+    # the trainer's fused Adam updates parameters without bumping `_version`: the packed copies must follow all the same
+    student.field.fused_state(student.density_scale)
+    emb_half = student.field._fused["tensors"][0]
+    assert torch.equal(emb_half, student.field.encoder.embeddings.detach().half())
