@@ -59,6 +59,58 @@ def get_encoder(encoding, input_dim=3, degree=4, num_levels=16, level_dim=2, bas
     return enc, enc.output_dim
 
 
+class _field_train(Function):
+    """NGPFieldFF.forward and its backward in native launches (csrc/render_fused.hip, "Training step of the field"): forward = one launch
+    that keeps 64 B per sample; backward = both networks recomputed, activation and weight gradients on the matrix cores (two launches),
+    then the table scatter.  Replaces ~40 op launches and ~1.5 KB per sample of saved / copied activations of the op-by-op graph.
+    Values follow the op-by-op path under autocast (same half roundings; weight gradients are summed in float32 and rounded once)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, d, embeddings, w_sigma, w_color, field):
+        x, d = x.contiguous(), d.contiguous()
+        M = x.shape[0]
+        L = _hip.lib()
+        f = field.fused_state(1.0)                       # the renderer applies density_scale itself (nerf/renderer.py:392)
+        sig = torch.empty(M, dtype=torch.float32, device=x.device)
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        saved = _hip.workspace(L.ngp_field_train_saved_bytes(M), x.device)
+        _hip.check(L.ngp_field_train_forward(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb), _hip.ptr(saved),
+                                             saved.numel(), _hip.stream()), "field_train_forward")
+        ctx.save_for_backward(x, d, saved, *field._fused["tensors"])
+        ctx.fstruct, ctx.field = f, field
+        return sig, rgb
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_sig, g_rgb):
+        x, d, saved, emb_half, ws_half, wc_half = ctx.saved_tensors
+        field, enc = ctx.field, ctx.field.encoder
+        M = x.shape[0]
+        L = _hip.lib()
+        g_sig = torch.zeros(M, dtype=torch.float32, device=x.device) if g_sig is None else g_sig.contiguous().float()
+        g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=x.device) if g_rgb is None else g_rgb.contiguous().float()
+        grad_enc = torch.empty(enc.num_levels, M, enc.level_dim, dtype=torch.float16, device=x.device)
+        g_ws = torch.empty(ws_half.numel(), dtype=torch.float32, device=x.device)
+        g_wc = torch.empty(wc_half.numel(), dtype=torch.float32, device=x.device)
+        work = _hip.workspace(L.ngp_field_train_workspace(M), x.device)
+        work[:L.ngp_field_train_workspace(0)].zero_()
+        _hip.check(L.ngp_field_train_backward(ctypes.byref(ctx.fstruct), _hip.ptr(saved), _hip.ptr(d), M, _hip.ptr(g_sig), _hip.ptr(g_rgb),
+                                              _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), _hip.stream()),
+                   "field_train_backward")
+        grad_emb = None
+        if ctx.needs_input_grad[2]:
+            inputs = ((x + field.bound) / (2 * field.bound)).contiguous()          # GridEncoder.forward (gridencoder/grid.py:144)
+            grad_emb = torch.zeros_like(emb_half)
+            dummy = torch.empty(1, dtype=torch.float16, device=x.device)
+            with _hip.timed("grid_encode_backward"):
+                _hip.check(L.ngp_grid_encode_backward(_hip.ptr(grad_enc), _hip.ptr(inputs), _hip.ptr(emb_half), _hip.ptr(enc.offsets), _hip.ptr(grad_emb),
+                                                      M, 3, enc.level_dim, enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, 0,
+                                                      _hip.ptr(dummy), _hip.ptr(dummy), enc.gridtype_id, int(enc.align_corners), _hip.F16, _hip.stream()),
+                           "grid_encode_backward")
+        return None, None, grad_emb, g_ws, g_wc, None
+
+
 class _ParamEpoch:
     """Cached derived copies of the parameters (half table, packed weights, the nav kernels' transposes) are keyed on the tensors'
     `_version` counters AND on this epoch.  Not every in-place update bumps `_version` (torch's fused Adam updates parameters without
@@ -89,9 +141,17 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         self.in_dim_color += geo_feat_dim + 1                      # padded to 32 (network_ff.py:42)
         self.color_net = FFMLP(input_dim=self.in_dim_color, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
         self._fused = None
+        self.fused_training = True           # training forwards under autocast go through _field_train when the field has the default shape
+
+    def _fused_training_applies(self, x, d):
+        p = self.encoder.embeddings
+        return (self.fused_training and x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and p.requires_grad
+                and p.dtype == torch.float32 and not x.requires_grad and not d.requires_grad and x.dim() == 2 and self._fused_shape_ok())
 
     def forward(self, x, d):
         self._training_forward()
+        if self._fused_training_applies(x, d):
+            return _field_train.apply(x, d, self.encoder.embeddings, self.sigma_net.weights, self.color_net.weights, self)
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])
@@ -155,14 +215,16 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
     def _check_fused_shape(self):
         """The one-launch kernels (csrc/render_fused.hip) are specialised for the reference's default field: 16 levels x 2 features of a
         3-D hash grid, density net 32-64-64-16, colour net 32-64-64-64-16.  Any other shape would be misread silently: refuse it."""
+        if not self._fused_shape_ok():
+            raise RuntimeError("the fused path supports the default field only (hash grid 16 x 2, FFMLP 32-64-64-16 and 32-64-64-64-16); "
+                               "use the per-op path (run_cuda / forward) for this configuration")
+
+    def _fused_shape_ok(self):
         e, sn, cn = self.encoder, self.sigma_net, self.color_net
-        ok = (e.num_levels == 16 and e.level_dim == 2 and e.input_dim == 3 and e.gridtype == "hash" and not e.align_corners
+        return (e.num_levels == 16 and e.level_dim == 2 and e.input_dim == 3 and e.gridtype == "hash" and not e.align_corners
               and sn.hidden_dim == 64 and cn.hidden_dim == 64 and sn.num_layers == 2 and cn.num_layers == 3
               and sn.input_dim == 32 and cn.input_dim == 32 and self.geo_feat_dim == 15
               and sn.weights.numel() == 7168 and cn.weights.numel() == 11264)
-        if not ok:
-            raise RuntimeError("the fused path supports the default field only (hash grid 16 x 2, FFMLP 32-64-64-16 and 32-64-64-64-16); "
-                               "use the per-op path (run_cuda / forward) for this configuration")
 
     def fused_state(self, density_scale=None):
         """Half copies of table and weights plus the ngp_field_t describing them (include/ngp_hip.h).  The reference

@@ -1,0 +1,70 @@
+"""GPU: the field's training step in native launches (ngp/field.py `_field_train`; csrc/render_fused.hip k_field_train_*) against the
+op-by-op autograd graph of the same module (GridEncoder -> FFMLP -> trunc_exp ; SH ++ geo -> FFMLP -> sigmoid; nerf/network_ff.py:51-77),
+which tests/test_gpu_callers_parity.py in turn pins against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(dev):
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    return NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(W.make_model(0)), W
+
+
+def _points(W, M, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * W.BOUND
+    x[::97] *= 1.3                                                     # a few samples outside the box: they encode to zeros
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    return x.to(dev), d.to(dev), torch.randn(M, generator=g).to(dev), torch.randn(M, 3, generator=g).to(dev)
+
+
+def _step(field, fused, x, d, gs, gc, scale):
+    field.fused_training = fused
+    for p in field.parameters():
+        p.grad = None
+    with torch.autocast("cuda", dtype=torch.float16):
+        sig, rgb = field(x, d)
+        loss = ((sig * gs).sum() + (rgb.float() * gc).sum()) * scale
+    loss.backward()
+    return (sig.detach().float(), rgb.detach().float(), field.encoder.embeddings.grad.clone(), field.sigma_net.weights.grad.clone(),
+            field.color_net.weights.grad.clone())
+
+
+@pytest.mark.parametrize("M", [4096, 5000, 37])
+def test_fused_training_step_equals_the_op_graph(dev, M):
+    field, W = _field(dev)
+    field.train()
+    x, d, gs, gc = _points(W, M, dev, seed=M)
+    ref = _step(field, False, x, d, gs, gc, 1.0)            # (a larger loss scale overflows the half gradients of BOTH paths on this model)
+    got = _step(field, True, x, d, gs, gc, 1.0)
+    # forward: the same half logits; exp / sigmoid are the library's own float32 routines (not torch's): a couple of ulps, and at most
+    # one half ulp after the sigmoid's rounding
+    assert float(((got[0] - ref[0]).abs() / ref[0]).max()) < 1e-6, "sigma"
+    assert float((got[1] - ref[1]).abs().max()) <= 2.0 ** -11 and float((got[1] != ref[1]).float().mean()) < 0.01, "rgb"
+    names = ["table", "density-net weights", "colour-net weights"]
+    for name, a, b in zip(names, got[2:], ref[2:]):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        scale = float(b.abs().max())
+        assert scale > 0 and bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all()), name
+        # same half roundings along the chain; the sums differ in order only (float atomics / one f32 sum rounded to half once)
+        err = float((a - b).abs().max())
+        assert err <= 1e-3 * scale, (name, err, scale)
+        assert float((a - b).abs().mean()) <= 1e-3 * float(b.abs().mean()) + 1e-9, name                     # (a half ulp is 5e-4 relative)
+
+
+def test_fused_training_is_used_only_where_it_applies(dev):
+    field, W = _field(dev)
+    x, d, gs, gc = _points(W, 256, dev, seed=1)
+    field.train()
+    assert field._fused_training_applies(x, d) is False                # no autocast: the reference's FFMLP refuses float32 anyway
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert field._fused_training_applies(x, d)
+        with torch.no_grad():
+            assert not field._fused_training_applies(x, d)             # density-grid refresh, evaluation
+        assert not field._fused_training_applies(x.clone().requires_grad_(True), d)    # gradients to the points: the op graph
+        field.encoder.embeddings.requires_grad_(False)
+        assert not field._fused_training_applies(x, d)                 # frozen table
