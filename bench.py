@@ -152,7 +152,7 @@ def bench_train(args, rank, world, dev, W, teacher):
             "value": rays_all / t_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"S-{args.workload} training (teacher-rendered 200x200 views), op-by-op HIP path with autograd, steady state after "
+            "config": {"workload": f"S-{args.workload} training (teacher-rendered 200x200 views), native field forward + backward, march, composite and table scatter under autograd, steady state after "
                                    f"{args.warmup + args.steps + args.settle} steps",
                        "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": loss},
             "roofline": roof(points, scatter_ms),

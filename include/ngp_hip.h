@@ -86,7 +86,7 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
 /* Validation switch, process-wide, default 1: with dt_gamma == 0 the count pass of ngp_march_rays_train marches one WAVE per ray (64 lattice
  * points per step, csrc/raymarching.hip: k_march_train_count_wave) instead of one lane per ray.  Same samples, counts and order either way;
  * returns the previous setting. */
-int ngp_march_set_wave_per_ray(int enabled);
+int ngp_march_set_wave_per_ray(int enabled);   /* also selects the wave-per-ray kernels of ngp_composite_rays_train_* */
 
 /* raymarching.h:14 composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
 int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,

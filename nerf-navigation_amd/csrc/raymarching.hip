@@ -509,6 +509,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_fill(march_args a,
 
 // validation switch: 0 = always march one lane per ray (tests compare the two count passes)
 static std::atomic<int> rm_wave_march_enabled{1};
+static constexpr uint32_t RM_WAVE_PER_RAY_MAX = 1u << 17;      // composite: from this many rays on, one lane per ray fills the chip by itself
 extern "C" int ngp_march_set_wave_per_ray(int enabled) { return rm_wave_march_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 static size_t rm_train_ws_base(uint32_t N) { return (sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4) + 255) & ~(size_t)255; }
@@ -653,14 +654,115 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_train_bwd(const floa
     }
 }
 
+// One WAVE per ray (training batches are a few thousand rays: one lane per ray leaves 94 % of the SIMDs idle and every lane waits for its own
+// loads).  The 64 lanes fetch 64 consecutive samples of the ray with coalesced loads and evaluate alpha = 1 - exp(-sigma delta) together;
+// the recurrences T, r, g, b, ... then run in the reference's order with the reference's arithmetic, every lane computing the same chain on
+// values broadcast with v_readlane: the results are the lane-per-ray kernel's, bit for bit (tests/test_gpu_raymarching.py compares them).
+static constexpr uint32_t RM_WAVES_PER_BLOCK = 4;
+__device__ __forceinline__ float rm_bcast(float v, uint32_t lane_uniform) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)lane_uniform));
+}
+
+__global__ __launch_bounds__(64 * RM_WAVES_PER_BLOCK) void k_composite_train_fwd_wave(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                                    const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                                    uint32_t M, uint32_t N, float* __restrict__ weights_sum,
+                                                                                    float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        if (lane == 0) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[3ull * index] = 0; image[3ull * index + 1] = 0; image[3ull * index + 2] = 0;
+        }
+        return;
+    }
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3ull * offset;
+    const float* dl = deltas + 2ull * offset;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    bool done = false;
+    for (uint32_t k0 = 0; k0 < num_steps && !done; k0 += 64) {
+        const uint32_t k = (k0 + lane < num_steps) ? k0 + lane : num_steps - 1;
+        const float sv = s[k], d0 = dl[2 * k], d1 = dl[2 * k + 1], c0 = c[3 * k], c1 = c[3 * k + 1], c2 = c[3 * k + 2];
+        const float alpha = 1.0f - ngp_expf(-sv * d0);
+        const uint32_t cnt = num_steps - k0 < 64u ? num_steps - k0 : 64u;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const float a = rm_bcast(alpha, j);
+            const float w = a * T;
+            r += w * rm_bcast(c0, j); g += w * rm_bcast(c1, j); b += w * rm_bcast(c2, j);
+            t += rm_bcast(d1, j);
+            d += w * t;
+            ws += w;
+            T *= 1.0f - a;
+            if (T < 1e-4f) { done = true; break; }
+        }
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws; depth[index] = d;
+        image[3ull * index] = r; image[3ull * index + 1] = g; image[3ull * index + 2] = b;
+    }
+}
+
+__global__ __launch_bounds__(64 * RM_WAVES_PER_BLOCK) void k_composite_train_bwd_wave(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+                                                                                    const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                                    const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                                    const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                                    uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
+                                                                                    float* __restrict__ grad_rgbs) {
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float g0 = grad_image[3ull * index], g1 = grad_image[3ull * index + 1], g2 = grad_image[3ull * index + 2];
+    const float rf = image[3ull * index], gf = image[3ull * index + 1], bf = image[3ull * index + 2], wsf = weights_sum[index];
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3ull * offset;
+    const float* dl = deltas + 2ull * offset;
+    float* gs = grad_sigmas + offset;
+    float* gc = grad_rgbs + 3ull * offset;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    bool done = false;
+    for (uint32_t k0 = 0; k0 < num_steps && !done; k0 += 64) {
+        const uint32_t k = (k0 + lane < num_steps) ? k0 + lane : num_steps - 1;
+        const float sv = s[k], d0 = dl[2 * k], c0 = c[3 * k], c1 = c[3 * k + 1], c2 = c[3 * k + 2];
+        const float alpha = 1.0f - ngp_expf(-sv * d0);
+        const uint32_t cnt = num_steps - k0 < 64u ? num_steps - k0 : 64u;
+        float mw = 0, mT = 0, mr = 0, mg = 0, mb = 0;          // the chain's values after this lane's sample
+        bool mine = false;                                     // (the sample on which T drops below 1e-4 gets no gradient, like every later one)
+        for (uint32_t j = 0; j < cnt; j++) {
+            const float a = rm_bcast(alpha, j);
+            const float w = a * T;
+            r += w * rm_bcast(c0, j); g += w * rm_bcast(c1, j); b += w * rm_bcast(c2, j);
+            T *= 1.0f - a;
+            if (T < 1e-4f) { done = true; break; }
+            if (lane == j) { mw = w; mT = T; mr = r; mg = g; mb = b; mine = true; }
+        }
+        if (mine) {
+            gc[3 * k] = g0 * mw; gc[3 * k + 1] = g1 * mw; gc[3 * k + 2] = g2 * mw;
+            gs[k] = d0 * (g0 * (mT * c0 - (rf - mr)) +
+                          g1 * (mT * c1 - (gf - mg)) +
+                          g2 * (mT * c2 - (bf - mb)) +
+                          gws * (1.0f - wsf));
+        }
+    }
+}
+
 extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                                 uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image, void* stream) {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null sample pointer");
     if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(ngp_div_up(N, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
-                       sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL(k_composite_train_fwd_wave, dim3(ngp_div_up(N, RM_WAVES_PER_BLOCK)), dim3(64 * RM_WAVES_PER_BLOCK), 0, (hipStream_t)stream,
+                           sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    else
+        hipLaunchKernelGGL(k_composite_train_fwd, dim3(ngp_div_up(N, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
+                           sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
     NGP_CHECK_LAUNCH("composite_rays_train_forward");
     return NGP_OK;
 }
@@ -673,8 +775,12 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
     NGP_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, "composite_rays_train_backward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), "composite_rays_train_backward: null sample pointer");
     if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(ngp_div_up(N, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
-                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL(k_composite_train_bwd_wave, dim3(ngp_div_up(N, RM_WAVES_PER_BLOCK)), dim3(64 * RM_WAVES_PER_BLOCK), 0, (hipStream_t)stream,
+                           grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    else
+        hipLaunchKernelGGL(k_composite_train_bwd, dim3(ngp_div_up(N, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
+                           grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
     NGP_CHECK_LAUNCH("composite_rays_train_backward");
     return NGP_OK;
 }

@@ -1795,7 +1795,10 @@ __device__ __forceinline__ void ft_train_forward_loop(const rf_params& P, const 
     }
 }
 
-__global__ __launch_bounds__(RF_BLOCK, RF_FIELD_WG_PER_CU) void k_field_train_forward(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
+#ifndef FT_FWD_WG_PER_CU
+#define FT_FWD_WG_PER_CU 3                // 144 VGPRs: three workgroups (12 waves) per CU hide more of the gather latency than two
+#endif
+__global__ __launch_bounds__(RF_BLOCK, FT_FWD_WG_PER_CU) void k_field_train_forward(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
                                                                       uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs,
                                                                       ngp_h8* __restrict__ enc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
@@ -2154,7 +2157,7 @@ extern "C" int ngp_field_train_forward(const ngp_field_t* field_host, const floa
                 ngp_field_train_saved_bytes(M));
     const uint32_t npairs = (M + 31) >> 5;
     uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
-    if (blocks > 256 * RF_FIELD_WG_PER_CU) blocks = 256 * RF_FIELD_WG_PER_CU;
+    if (blocks > 256 * FT_FWD_WG_PER_CU) blocks = 256 * FT_FWD_WG_PER_CU;
     hipLaunchKernelGGL(k_field_train_forward, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs, (ngp_h8*)saved);
     NGP_CHECK_LAUNCH("field_train_forward");
     return NGP_OK;

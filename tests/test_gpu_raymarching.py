@@ -251,7 +251,19 @@ def test_march_rays_train_matches_iterated_march_rays(oracle, scene):
         assert np.array_equal(x1[:k].view(np.uint32), x_r[off:off + cnt].view(np.uint32))
 
 
-def test_composite_rays_train_forward_backward(oracle, dev, scene):
+@pytest.mark.parametrize("wave_per_ray", [1, 0], ids=["wave_per_ray", "lane_per_ray"])
+def test_composite_rays_train_forward_backward(oracle, dev, scene, wave_per_ray):
+    """both kernel shapes (one wave per ray for training-sized batches, one lane per ray otherwise) against the oracle, bit for bit"""
+    import ngp_hip
+    import raymarching
+    previous = ngp_hip.lib().ngp_march_set_wave_per_ray(wave_per_ray)
+    try:
+        _composite_rays_train_forward_backward(oracle, dev, scene)
+    finally:
+        ngp_hip.lib().ngp_march_set_wave_per_ray(previous)
+
+
+def _composite_rays_train_forward_backward(oracle, dev, scene):
     import raymarching
     o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
     x, _, l, rays = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, None, 30000, True, 128, False, 0.0, 1024)
