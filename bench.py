@@ -39,7 +39,7 @@ ATOMIC_PEAK_GBS = 1300.0               # MI355X_MICROARCH.md "Global float atomi
 SCATTER_BYTES_PER_POINT = 512          # 16 levels x 8 corners x 2 features x 2 B of half2 atomics (SURVEY 8d "training extra")
 
 
-FRAME_SOURCES = ("render_fused.hip", "ngp_device.h", "ngp_march.h", "ngp_mlp.h", "ngp_sh.h", "ngp_camera.h", "Makefile")   # what k_render_frame_multi is built from
+FRAME_SOURCES = ("render_fused.hip", "ngp_field.h", "ngp_device.h", "ngp_march.h", "ngp_mlp.h", "ngp_sh.h", "ngp_camera.h", "Makefile")   # what k_render_frame_multi is built from
 TRAIN_SOURCES = ("gridencoder.hip", "ngp_device.h", "Makefile")                                                              # ... and k_grid_backward
 
 

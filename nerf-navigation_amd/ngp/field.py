@@ -60,7 +60,7 @@ def get_encoder(encoding, input_dim=3, degree=4, num_levels=16, level_dim=2, bas
 
 
 class _field_train(Function):
-    """NGPFieldFF.forward and its backward in native launches (csrc/render_fused.hip, "Training step of the field"): forward = one launch
+    """NGPFieldFF.forward and its backward in native launches (csrc/field_train.hip): forward = one launch
     that keeps 64 B per sample; backward = both networks recomputed, activation and weight gradients on the matrix cores (two launches),
     then the table scatter.  Replaces ~40 op launches and ~1.5 KB per sample of saved / copied activations of the op-by-op graph.
     Values follow the op-by-op path under autocast (same half roundings; weight gradients are summed in float32 and rounded once)."""

@@ -28,7 +28,7 @@ def test_no_single_rounding_conversions_in_the_shipped_kernels(tmp_path):
     this checks the optimised ISA of every kernel file for the instruction."""
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(ROOT, "nerf-navigation_amd", "csrc")
-    files = ["raymarching", "gridencoder", "shencoder", "freqencoder", "ffmlp", "ffmlp_backward", "render_fused"]
+    files = ["raymarching", "gridencoder", "shencoder", "freqencoder", "ffmlp", "ffmlp_backward", "render_fused", "field_train"]
     flags = [f for f in FLAGS if f not in ("-O1", "-c", "-Werror")] + ["-O3", "-S"]      # (-S leaves hipcc's --hip-link unused: a warning)
 
     def isa(name):
@@ -60,3 +60,10 @@ def test_fused_kernels_do_not_spill(tmp_path):
     frame = next(v for n, v in res.items() if "k_render_frame_multi" in n)
     assert field["spill"] == 0 and frame["spill"] == 0, (field, frame)
     assert field["vgpr"] <= 256 and frame["vgpr"] <= 256
+    # the training step: the backward runs one wave per SIMD so that the accumulator tiles of the weight gradients (44 / 28 x 4 registers)
+    # fit beside two tiles of activations; all 72 in one kernel spilled 110 registers, hence its two parts
+    src = os.path.join(ROOT, "nerf-navigation_amd", "csrc", "field_train.hip")
+    out = subprocess.run([HIPCC] + flags + [src, "-o", str(tmp_path / "ft.s")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    train = [k for k in kernels(open(tmp_path / "ft.s").read()) if "k_field_train" in k["name"]]
+    assert len(train) == 4 and all(k["spill"] == 0 for k in train), train

@@ -1,4 +1,4 @@
-"""GPU: the field's training step in native launches (ngp/field.py `_field_train`; csrc/render_fused.hip k_field_train_*) against the
+"""GPU: the field's training step in native launches (ngp/field.py `_field_train`; csrc/field_train.hip) against the
 op-by-op autograd graph of the same module (GridEncoder -> FFMLP -> trunc_exp ; SH ++ geo -> FFMLP -> sigmoid; nerf/network_ff.py:51-77),
 which tests/test_gpu_callers_parity.py in turn pins against the oracle."""
 import numpy as np
