@@ -895,7 +895,7 @@ static int march_rays_launch(bool fill, uint32_t M, uint32_t n_alive, uint32_t n
     const size_t cbytes = (workspace && n_alive) ? rm_coarse_bytes(grid, C, H) : 0;
     const size_t lds = (cbytes && workspace_bytes >= cbytes) ? cbytes : 0;
     if (lds) rm_attach_coarse(a, workspace, (hipStream_t)stream);
-    const bool big = n_alive >= 65536u;
+    const bool big = n_alive >= 65536u;          // (measured: the frame takes the same time with 64-thread workgroups throughout; 256 stage the map 4x less often)
     const uint32_t bs = big ? RM_BLOCK : RM_RAY_BLOCK;
     const dim3 grid_dim(ngp_div_up(n_alive ? n_alive : 1, bs)), block(bs);
     hipStream_t st = (hipStream_t)stream;
