@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank renders its own frames (headline); strong = every frame is cut into row bands, one per rank")
     ap.add_argument("--gather", action="store_true", help="strong scaling: all-gather the row bands into the full image on every rank, inside the timed region")
-    ap.add_argument("--settle", type=int, default=160, help="train mode: untimed steps between the warm-up phase and the steady-state phase")
+    ap.add_argument("--settle", type=int, default=1460, help="train mode: untimed steps between the warm-up phase and the steady-state phase")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render = the headline metric; train = secondary: training steps (configs 3 / 5), 4096 rays per step per GPU")
     args = ap.parse_args()
