@@ -1,5 +1,6 @@
 """Packing / march statistics of one fused 800x800 frame (needs a -DRV_COUNTERS build for rounds and march trips):
-   NGP_HIP_LIB=.../libngp_counters.so python tools/frame_counters.py"""
+   NGP_HIP_LIB=.../libngp_counters.so python tools/frame_counters.py [res] [--trained STEPS]
+--trained STEPS renders a student fitted for STEPS steps to the hand-set scene (bench.py --model trained) instead of the hand-set model."""
 import importlib
 import os
 import sys
@@ -15,11 +16,17 @@ from ngp.field import NGPFieldFF  # noqa: E402
 from ngp.render import NGPRenderer  # noqa: E402
 
 dev = torch.device("cuda:0")
-res = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+trained = int(sys.argv[sys.argv.index("--trained") + 1]) if "--trained" in sys.argv else 0
+res = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 800
 model = W.make_model(0)
 field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(model)
 ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
 ren.load_density_grid(W.density_grid())
+if trained:
+    import argparse
+    import bench
+    ren, fit = bench.fit_model(argparse.Namespace(workload="ring", fit_steps=trained), dev, W, ren)
+    print("student:", fit)
 o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(res, res), res, res)
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 for _ in range(3):                                      # warm-up launches: the counters below are those of a warm frame

@@ -22,6 +22,7 @@ ap.add_argument("kernels", nargs="*", default=["k_render_frame"])
 ap.add_argument("--title", default="bench.py, 800x800 S-ring, 1x MI355X")
 ap.add_argument("--top", type=int, default=0)
 ap.add_argument("--dst", default=None, help="output directory (default: profiles/ of the repository)")
+ap.add_argument("--last", type=int, default=0, help="counter means over the LAST N dispatches of the first kernel only (a run that launches it on other inputs first)")
 ap.add_argument("--sources", default="frame", choices=["frame", "train"], help="which kernel's source set the recorded hash covers")
 args = ap.parse_args()
 tag = args.tag
@@ -78,7 +79,10 @@ for f in sorted(sum((newest(os.path.join(d, "*", "*counter_collection.csv")) for
         if args.kernels[0] in r["Kernel_Name"]:
             agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, v in agg.items():
-        counters[k] = sum(v.values()) / len(v)
+        vals = [v[d] for d in sorted(v, key=int)]
+        if args.last:
+            vals = vals[-args.last:]
+        counters[k] = sum(vals) / len(vals)
 with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as f:
     f.write("counter,mean_per_dispatch\n")
     for k in sorted(counters):
@@ -110,6 +114,8 @@ if bench and "ms_per_step" in bench:
     lines.append(f"* the command's own line under the profiler: {bench['ms_per_step']:.3f} ms/step{extra}")
 if c("FETCH_SIZE") is not None:
     fetch, write = c("FETCH_SIZE") * 1024, (c("WRITE_SIZE") or 0) * 1024
+    if args.last:
+        lines.append(f"* counters below: means over the last {args.last} dispatches of `{args.kernels[0]}`")
     lines.append(f"* `{args.kernels[0]}` fabric traffic per launch: FETCH_SIZE {fetch / 1e9:.3f} GB + WRITE_SIZE {write / 1e9:.3f} GB "
                  f"(TCC_EA0_RDREQ x 64 B = {(c('TCC_EA0_RDREQ_sum') or 0) * 64 / 1e9:.3f} GB; scattered 4/8-byte accesses, so the guide's 2x "
                  f"wide-stream correction does not apply; L2-miss traffic, an upper bound on HBM bytes)")
