@@ -124,8 +124,8 @@ __device__ __forceinline__ void nv_level_grad(const nav_params& P, int l, float 
 
 // world position -> normalised position (grid.py:144); `inside` false = outside [0,1]^3 (or NaN): the encoder returns zeros (gridencoder.cu:99-123)
 __device__ __forceinline__ bool nv_normalise(const nav_params& P, float wx, float wy, float wz, float& x0, float& x1, float& x2) {
-    if (P.r2b != 0.0f) { x0 = (wx + P.bound) * P.r2b; x1 = (wy + P.bound) * P.r2b; x2 = (wz + P.bound) * P.r2b; }
-    else { const float b2 = 2.0f * P.bound; x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
+    // torch on the GPU divides by a host scalar by multiplying with its binary32 reciprocal (ATen BinaryDivTrueKernel.cu): r2b = fl(1 / (2 bound))
+    x0 = (wx + P.bound) * P.r2b; x1 = (wy + P.bound) * P.r2b; x2 = (wz + P.bound) * P.r2b;
     const bool inside = (x0 >= 0.0f && x0 <= 1.0f) && (x1 >= 0.0f && x1 <= 1.0f) && (x2 >= 0.0f && x2 <= 1.0f);
     if (!inside) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; }                     // gather somewhere valid; the features are discarded
     return inside;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void nv_density_backward(const nav_params& P, bool in
         for (int j = 0; j < NV_H; j++) g1 = __builtin_fmaf(wb[j], gh[j], g1);
         nv_level_grad(P, l, x0, x1, x2, g0, g1, ax, ay, az);
     }
-    const float k = inside ? (P.r2b != 0.0f ? P.r2b : 1.0f / (2.0f * P.bound)) : 0.0f;       // d x01 / d world; zero outside the box
+    const float k = inside ? P.r2b : 0.0f;                                                 // d x01 / d world; zero outside the box
     gx = ax * k; gy = ay * k; gz = az * k;
 }
 
@@ -648,8 +648,7 @@ static int nav_fill(const char* who, const ngp_nav_field_t* f, const void* prepa
     }
     sh_fill_norm(P.shn);
     P.bound = f->bound;
-    int e;
-    P.r2b = frexpf(2.0f * f->bound, &e) == 0.5f ? 1.0f / (2.0f * f->bound) : 0.0f;      // exact reciprocal only for powers of two
+    P.r2b = 1.0f / (2.0f * f->bound);
     P.density_scale = f->density_scale;
     return NGP_OK;
 }

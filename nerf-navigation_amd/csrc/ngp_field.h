@@ -32,7 +32,7 @@ struct rf_params {
     const _Float16* w_sigma;          // 64*(32+64+16)
     const _Float16* w_color;          // 64*(32+128+16)
     float bound, density_scale;
-    float inv_b2;                     // 1 / (2 bound) when that is exact (2 bound a power of two), else 0
+    float inv_b2;                     // fl(1 / (2 bound)): the reciprocal torch multiplies by
     float scale[RF_L];                // exp2f(l*S)*H - 1 (host)
     uint32_t resolution[RF_L];        // ceil(scale)+1
     sh_norm shn;
@@ -124,11 +124,10 @@ __device__ __forceinline__ rf_row2 rf_rows(const rf_params& P, uint32_t byte_off
 struct rf_pair { uint32_t raw[2][8]; float fx[2], fy[2], fz[2]; };
 
 __device__ __forceinline__ void rf_normalise(const rf_params& P, float wx, float wy, float wz, float& x0, float& x1, float& x2) {
-    // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound).  When 2*bound is a power of two (every cascade-aligned
-    // bound) the quotient equals the product with the exact reciprocal, bit for bit, and skips three IEEE divisions.
-    const float b2 = 2 * P.bound;
-    if (P.inv_b2 != 0.0f) { x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2; }
-    else { x0 = (wx + P.bound) / b2; x1 = (wy + P.bound) / b2; x2 = (wz + P.bound) / b2; }
+    // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound) -- as torch evaluates it on the GPU: a tensor divided by a host scalar is the
+    // product with the scalar's binary32 reciprocal (ATen BinaryDivTrueKernel.cu: "compute a * reciprocal(b)").  For a power-of-two 2 * bound
+    // that is the exact quotient; for any other bound it is what the reference's encoder sees, one rounding away from the quotient at times.
+    x0 = (wx + P.bound) * P.inv_b2; x1 = (wy + P.bound) * P.inv_b2; x2 = (wz + P.bound) * P.inv_b2;
 }
 
 template <int H>
@@ -316,11 +315,7 @@ static inline int rf_fill_params(const char* who, const ngp_field_t* f, rf_param
     P.w_color = (const _Float16*)f->color_weights;
     P.bound = f->bound;
     P.density_scale = f->density_scale;
-    {
-        int e;
-        const float b2 = 2.0f * f->bound;
-        P.inv_b2 = (frexpf(b2, &e) == 0.5f) ? 1.0f / b2 : 0.0f;
-    }
+    P.inv_b2 = 1.0f / (2.0f * f->bound);
     for (int l = 0; l < RF_L; l++) {
         P.scale[l] = exp2f((float)l * f->S) * (float)f->H - 1.0f;
         P.resolution[l] = (uint32_t)ceilf(P.scale[l]) + 1u;

@@ -62,7 +62,9 @@ def grid_encode(x, embeddings, offsets, per_level_scale, base_resolution=16, bou
     """GridEncoder.forward (grid.py:140-156): x [B,3] world coordinates in [-bound, bound] -> [B, L*C] in the dtype of `embeddings`
     (float32 or float64).  Differentiable w.r.t. x and embeddings."""
     dt = embeddings.dtype
-    x01 = (x.to(dt) + bound) / (2 * bound)                            # grid.py:144
+    # grid.py:144 `(inputs + bound) / (2 * bound)` as the reference evaluates it on its GPU: torch divides a tensor by a host scalar by multiplying
+    # with the scalar's reciprocal in the tensor's dtype (ATen BinaryDivTrueKernel.cu).  Exact for a power-of-two 2 * bound.
+    x01 = (x.to(dt) + bound) * torch.tensor(1.0, dtype=dt).div(torch.tensor(2 * bound, dtype=dt))
     B, D = x01.shape
     L = len(offsets) - 1
     S = np.float32(np.log2(per_level_scale))                          # grid.py:33: narrowed to float at the boundary

@@ -23,7 +23,9 @@ def field_forward(model, xyzs, dirs, density_scale=1.0):
     x = np.ascontiguousarray(xyzs, np.float32)
     d = np.ascontiguousarray(dirs, np.float32)
     M = x.shape[0]
-    x01 = ((x + bound) / (np.float32(2) * bound)).astype(np.float32)                    # gridencoder/grid.py:144
+    # gridencoder/grid.py:144, `(inputs + bound) / (2 * bound)`, as torch evaluates it on the reference's GPU: the product with the binary32
+    # reciprocal of the host scalar (ATen BinaryDivTrueKernel.cu); the exact quotient when 2 * bound is a power of two
+    x01 = ((x + np.float32(bound)) * (np.float32(1) / (np.float32(2) * np.float32(bound)))).astype(np.float32)
     emb = model["embeddings"].astype(np.float16)                                        # grid.py:38-39 (autocast)
     feats, _ = O.grid_encode_forward(x01, emb, model["offsets"], model["per_level_scale"], 16, False, 0, False)
     feats = np.ascontiguousarray(feats.transpose(1, 0, 2).reshape(M, 32))               # grid.py:52
