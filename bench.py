@@ -207,9 +207,10 @@ def main():
                          "renders of it with the package's own trainer for --fit-steps steps, seed 0 (SURVEY 8d), then rendered")
     ap.add_argument("--fit-steps", type=int, default=2000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "per_op", "per_op_fused_field"],
+    ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "drop_in", "per_op", "per_op_fused_field"],
                     help="fused = headline (rays resident); fused_camera = rays generated inside the frame kernel from the pose; "
-                         "fused_torch_rays = torch get_rays per frame + fused; per_op = the reference-shaped op-by-op loop")
+                         "fused_torch_rays = torch get_rays per frame + fused; drop_in = run_cuda as an unmodified renderer runs it (the field picks its one-launch route); "
+                         "per_op = the same loop with every op of the field on its own; per_op_fused_field = the one-launch field called explicitly")
     ap.add_argument("--workload", default="ring", choices=["ring", "church"],
                     help="ring = S-ring, the BASELINE config-2 stand-in (headline); church = the larger shell scene of config 5")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -297,7 +298,9 @@ def main():
             return out
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024,
-                                fused_field=(args.path == "per_op_fused_field"))
+                                fused_field={"drop_in": None, "per_op": False, "per_op_fused_field": True}[args.path])
+            # drop_in: the loop as an unmodified renderer runs it (NGPFieldFF.forward takes its one-launch route by itself); per_op: every op of
+            # the field on its own; per_op_fused_field: the one-launch field called explicitly
 
     def sync_all():
         torch.cuda.synchronize()

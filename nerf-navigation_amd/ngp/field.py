@@ -142,16 +142,27 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         self.color_net = FFMLP(input_dim=self.in_dim_color, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
         self._fused = None
         self.fused_training = True           # training forwards under autocast go through _field_train when the field has the default shape
+        self.fused_inference = True          # forwards without gradients under autocast go through forward_fused (one launch), likewise
 
     def _fused_training_applies(self, x, d):
         p = self.encoder.embeddings
         return (self.fused_training and x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and p.requires_grad
                 and p.dtype == torch.float32 and not x.requires_grad and not d.requires_grad and x.dim() == 2 and self._fused_shape_ok())
 
+    def _fused_inference_applies(self, x, d):
+        return (self.fused_inference and x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled() and x.dim() == 2
+                and self.encoder.embeddings.dtype == torch.float32 and self._fused_shape_ok())
+
     def forward(self, x, d):
+        """sigma [M] float32, rgb [M,3] (half under autocast) as nerf/network_ff.py:51-77 returns them.  Under autocast the default field takes
+        one native launch when nothing is differentiated (`forward_fused`: what an unmodified renderer's inference loop gets per iteration
+        instead of ~25 small launches) and three when the parameters are (`_field_train`); every other case runs op by op."""
         self._training_forward()
         if self._fused_training_applies(x, d):
             return _field_train.apply(x, d, self.encoder.embeddings, self.sigma_net.weights, self.color_net.weights, self)
+        if self._fused_inference_applies(x, d):
+            sigma, rgb = self.forward_fused(x, d, density_scale=1.0)
+            return sigma, rgb.to(torch.float16)      # (the values are halves already)
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])

@@ -103,7 +103,7 @@ class NGPRenderer(nn.Module):
     # occupancy-grid path, op by op
     # ------------------------------------------------------------------------------------------------------------
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
-                 trace=None, fused_field=False, **kwargs):
+                 trace=None, fused_field=None, **kwargs):
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -146,8 +146,20 @@ class NGPRenderer(nn.Module):
                     # the reference's loop and schedule, but encoder + both MLPs + activations in ONE launch per iteration
                     # (ngp_field_forward: sigma already times the renderer's density_scale) instead of ~25 small ones
                     sigmas, rgbs = self.field.forward_fused(xyzs, dirs, density_scale=self.density_scale)
-                else:
+                elif fused_field is None:
+                    # the reference's two lines (nerf/renderer.py:360-361); NGPFieldFF.forward itself takes the one-launch route when it applies
                     sigmas, rgbs = self(xyzs, dirs)
+                    sigmas = self.density_scale * sigmas
+                else:
+                    # fused_field=False: every op of the field separately (the parity anchor of the drop-in ops)
+                    keep = getattr(self.field, "fused_inference", None)
+                    if keep is not None:
+                        self.field.fused_inference = False
+                    try:
+                        sigmas, rgbs = self(xyzs, dirs)
+                    finally:
+                        if keep is not None:
+                            self.field.fused_inference = keep
                     sigmas = self.density_scale * sigmas
                 raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
                 if trace is not None:

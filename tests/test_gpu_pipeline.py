@@ -71,9 +71,16 @@ def test_field_per_op_vs_fused(setup, oracle, dev):
     """NeRFNetwork.forward through the drop-in packages under autocast vs the one-launch field kernel."""
     x, d = sample_points(setup, oracle)
     field = setup["field"].eval()
+    field.fused_inference = False                                       # the op graph ...
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            sig, rgb = field(t(x, dev), t(d, dev))
+    finally:
+        field.fused_inference = True
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        sig, rgb = field(t(x, dev), t(d, dev))
+        sig_a, rgb_a = field(t(x, dev), t(d, dev))                      # ... the same call as an unmodified renderer makes it: one launch
     sig_f, rgb_f = field.forward_fused(t(x, dev), t(d, dev))
+    assert sig_a.dtype == torch.float32 and rgb_a.dtype == torch.float16 and torch.equal(sig_a, sig_f) and torch.equal(rgb_a.float(), rgb_f)
     assert sig.dtype == torch.float32 and rgb.dtype == torch.float16
     # same gather and same density net => the logits are identical; only torch.exp vs ngp_expf differs (<= 2 ulp)
     np.testing.assert_allclose(sig.cpu().numpy(), sig_f.cpu().numpy(), rtol=3e-7)
@@ -86,7 +93,8 @@ def test_run_cuda_per_op_loop_vs_oracle(setup, oracle, dev):
     tr_ref, tr = [], []
     ref = R.run_cuda(lambda x, d: R.field_forward(model, x, d, 1.0), setup["o"], setup["d"], setup["bitfield"], 2.0, 2, trace=tr_ref)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        out = ren.run_cuda(t(setup["o"], dev)[None], t(setup["d"], dev)[None], dt_gamma=0, bg_color=1, perturb=False, max_steps=1024, trace=tr)
+        out = ren.run_cuda(t(setup["o"], dev)[None], t(setup["d"], dev)[None], dt_gamma=0, bg_color=1, perturb=False, max_steps=1024, trace=tr,
+                           fused_field=False)
     img = out["image"][0].cpu().numpy()
     assert img.shape == (HW * HW, 3)
     # the alive-count schedule is an integer function of every termination decision: compare it step by step
@@ -125,7 +133,7 @@ def test_render_fused_matches_per_op_loop(setup, dev):
     ren, W = setup["ren"], setup["W"]
     o, d = W.get_rays(W.orbit_pose(5), W.intrinsics(HW, HW), HW, HW)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        a = ren.run_cuda(t(o, dev)[None], t(d, dev)[None], bg_color=1)
+        a = ren.run_cuda(t(o, dev)[None], t(d, dev)[None], bg_color=1, fused_field=False)
     b = ren.render_fused(t(o, dev)[None], t(d, dev)[None], bg_color=1)
     assert np.max(np.abs(a["image"].cpu().numpy() - b["image"].cpu().numpy())) < 5e-3
 
@@ -149,8 +157,10 @@ def test_run_cuda_with_fused_field_matches_the_per_op_loop(setup, dev):
     o, d = t(o, dev)[None], t(d, dev)[None]
     ta, tb = [], []
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        a = ren.run_cuda(o, d, bg_color=1, trace=ta)
+        a = ren.run_cuda(o, d, bg_color=1, trace=ta, fused_field=False)
         b = ren.run_cuda(o, d, bg_color=1, trace=tb, fused_field=True)
+        c = ren.run_cuda(o, d, bg_color=1)                                              # default: the field decides (= one launch here)
+    assert torch.equal(b["image"], c["image"]) and torch.equal(b["depth"], c["depth"])
     assert [x[:2] for x in ta[:20]] == [x[:2] for x in tb[:20]]                       # the first iterations: identical schedule
     assert abs(sum(x[2] for x in ta) - sum(x[2] for x in tb)) <= max(8, 2e-4 * sum(x[2] for x in ta))
     assert float((a["image"] - b["image"]).abs().max()) < 2e-3
