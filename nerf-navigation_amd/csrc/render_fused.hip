@@ -79,6 +79,19 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 #ifndef RV_XCD_QUEUES
 #define RV_XCD_QUEUES 1        // 1: eight ray queues, one per XCD (image bands), with stealing; 0: one global queue
 #endif
+// Coherence knobs (round 2; same images, tools/ab_variants.sh and tools/ab_trained.sh: ms per 800x800 frame of the hand-set model | G ray-samples/s on
+// a model fitted for 2,000 and for 8,000 steps).  Lane l of a wave gathers for the samples of ray l; what the 64 addresses of one gather instruction
+// share (cells of the coarse and middle levels, i.e. cache lines) decides how fast a CU's texture path and L1 turn a tile around.
+#ifndef RV_REFILL_MIN
+#define RV_REFILL_MIN 64       // a wave draws new rays only when this many of its lanes are free.  64 = a whole 8x8 pixel tile at a time: the rays of a wave stay
+#endif                         // neighbours for life (1 = any free lane takes the next ray of the queue at once; after a few rounds a wave holds rays of many
+                               // tiles at unrelated depths).   1: 3.78 | 3.73, 4.36    16: 3.84 | 4.43    32: - | 4.88    48: 3.60 | -, 4.95    64: 3.45-3.49 | 5.3-5.5, 5.1-5.3
+#ifndef RV_SLAB_STEPS
+#define RV_SLAB_STEPS 16       // a round's samples lie within this many steps behind the wave's FRONT = the nearest next sample of its 64 rays (march phase of
+#endif                         // k_render_frame_multi): neighbouring rays are sampled at the same depth together, whatever empty space each crossed before.
+                               // 0 (off): 3.49 | 5.3, 5.3    8: 3.53 | 8.1, 6.7    12: 3.51 | 7.8    16: 3.46 | 8.1, 6.9    24: 3.45 | 7.7, 6.6    32: 3.46 | 7.3, 6.5    48: 3.49 | 6.7
+                               // (limiting every lane to (smallest t of the wave) + 24 steps instead -- the laggard crawls through its empty space 24 steps a
+                               //  round -- gave 7.4-7.7 on the fitted model but 4.06 ms on the hand-set one: rounds of 87 samples instead of 636)
 #ifndef RV_BLOCK_THREADS
 #define RV_BLOCK_THREADS 512
 #endif
@@ -619,7 +632,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
     for (;;) {
         if (!exhausted) {
             const unsigned long long need = __ballot(!active);
-            if (need) {
+            if (need && (uint32_t)__popcll(need) >= RV_REFILL_MIN) {
                 const uint32_t cnt = (uint32_t)__popcll(need);
                 uint32_t base = 0;
 #if RV_XCD_QUEUES
@@ -689,7 +702,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
         n_rounds++;
         const unsigned long long rv_live = __ballot(active);
 #endif
-        if (active) {
+        {
             // The ray's constants live across the field evaluation, where every register is taken, so the allocator keeps them
             // in scratch; without this copy it reloads them at each use inside the probe loop (10 scratch loads per probe on
             // the march's critical path).  The copy is defined here and dies with the loop: one reload per round.
@@ -701,31 +714,51 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             // vector registers; a copy per round keeps every memory access out of the probe loop
             rv_consts Kr = K;
             asm("" : "+v"(Kr.Hf), "+v"(Kr.Hm1), "+v"(Kr.Cf), "+v"(Kr.rH), "+v"(Kr.dt_min), "+v"(Kr.dt_max), "+v"(Kr.rbound), "+v"(Kr.H3));
-            const float M = F.skip ? ngp_skip_margin(mr, K.bound, far_r) : __builtin_inff();
+            const float M = (active && F.skip) ? ngp_skip_margin(mr, K.bound, far_r) : __builtin_inff();
             // this lane's slots, recomputed from the lane id (2 VALU) rather than kept across the field evaluation in scratch
             const uint32_t slot0 = ((uint32_t)wave_s * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) * RV_S;
             float4* const smp_w = lds_smp + slot0;
             int probes = 0;
-            for (;;) {
+            float t_lim = __builtin_inff();
+            // the probe loop: collects samples while cnt < upto and t < t_lim
+            auto march = [&](int upto) {
+                for (;;) {
 #ifdef RV_COUNTERS
-                n_trips = __builtin_amdgcn_readfirstlane(n_trips) + 1;
+                    n_trips = __builtin_amdgcn_readfirstlane(n_trips) + 1;
 #endif
-                if (!(t < far_r && nsamp < F.max_steps)) { ended = true; break; }
-                float x, y, z, dt;
+                    if (!(t < far_r && nsamp < F.max_steps)) { ended = true; break; }
+                    if (RV_SLAB_STEPS > 0 && !(t < t_lim)) break;
+                    float x, y, z, dt;
 #ifdef RV_COUNTERS
-                int pc = 0;
-                const bool hit = rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt, &pc);
-                n_probe[pc]++;
-                if (hit) {
+                    int pc = 0;
+                    const bool hit = rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt, &pc);
+                    n_probe[pc]++;
+                    if (hit) {
 #else
-                if (rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt)) {
+                    if (rv_probe<RV_BLOCK_SKIP != 0>(mr, Kr, lds_coarse, F.coarse_words, M, bc, t, x, y, z, dt)) {
 #endif
-                    smp_w[cnt] = make_float4(x, y, z, t);     // the compositor re-derives dt and t - last_t from t (same operations)
-                    t += dt;
-                    nsamp++;
-                    if (++cnt == RV_S) break;
+                        smp_w[cnt] = make_float4(x, y, z, t);     // the compositor re-derives dt and t - last_t from t (same operations)
+                        t += dt;
+                        nsamp++;
+                        if (++cnt >= upto) break;
+                    }
+                    if (++probes >= RF_PROBES_PER_ROUND) break;
                 }
-                if (++probes >= RF_PROBES_PER_ROUND) break;
+            };
+            if (RV_SLAB_STEPS > 0) {
+                // Depth slab: every lane first finds its NEXT sample (crossing whatever empty space lies before it), the wave takes the nearest of
+                // those as its front, and only lanes whose next sample lies within RV_SLAB_STEPS steps of the front sample this round; the others
+                // put theirs back (t returns to it: one probe finds it again next round) and wait for the front to reach them.
+                if (active) march(1);
+                const float t_first = cnt ? smp_w[0].w : __builtin_inff();
+                float tf = t_first;
+                #pragma unroll
+                for (int off = 1; off < 64; off <<= 1) tf = fminf(tf, __shfl_xor(tf, off, 64));
+                t_lim = tf + (float)RV_SLAB_STEPS * K.dt_min;
+                if (cnt && !(t_first < t_lim)) { t = t_first; nsamp--; cnt = 0; ended = false; }
+                if (active && cnt && !ended) march(RV_S);
+            } else if (active) {
+                march(RV_S);
             }
         }
 
