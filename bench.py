@@ -50,7 +50,15 @@ def sources_sha16(files=FRAME_SOURCES):
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "nerf-navigation_amd", "csrc")
     for name in files:
-        h.update(open(os.path.join(csrc, name), "rb").read())
+        data = open(os.path.join(csrc, name), "rb").read()
+        if name == "Makefile":                         # only what reaches the compiler: tool, architecture, flags (not the list of source files)
+            keep, cont = [], False
+            for line in data.decode().splitlines():
+                if cont or line.startswith(("HIPCC", "ARCH", "HIPFLAGS")):
+                    keep.append(line)
+                    cont = line.rstrip().endswith("\\")
+            data = "\n".join(keep).encode()
+        h.update(data)
     return h.hexdigest()[:16]
 
 

@@ -9,6 +9,7 @@
 //   inference : same without the activation stores
 // FLOPs per sample = 2 * (64*in + 64*64*(num_layers-1) + 64*16).
 #include "ngp_mlp.h"
+#include "ngp_ffmlp_generic.h"
 
 template <int NHID, int INC, bool SAVE>
 __global__ __launch_bounds__(256) void k_ffmlp_forward(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
@@ -89,6 +90,17 @@ static int ffmlp_dispatch(bool save, const void* X, const void* W, uint32_t B, u
 extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                                  uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                                  void* forward_buffer, void* outputs, void* stream) {
+    if (!ffmlp_fast_shape(input_dim, output_dim, hidden_dim, num_layers, activation, output_activation)) {
+        // every other shape / activation of the reference's module: layer by layer (ffmlp_generic.hip)
+        int rg = ffmlp_generic_check("ffmlp_forward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+        if (rg != NGP_OK) return rg;
+        if (B == 0) return NGP_OK;
+        NGP_REQUIRE(inputs && weights && outputs && forward_buffer, "ffmlp_forward: null pointer");
+        rg = ffmlp_generic_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, forward_buffer, outputs, (hipStream_t)stream);
+        if (rg != NGP_OK) return rg;
+        NGP_CHECK_LAUNCH("ffmlp_forward");
+        return NGP_OK;
+    }
     int rc = ffmlp_check("ffmlp_forward", inputs, weights, outputs, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NGP_OK) return rc;
     if (B == 0) return NGP_OK;
@@ -102,6 +114,16 @@ extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32
 extern "C" int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                                    uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                                    void* inference_buffer, void* outputs, void* stream) {
+    if (!ffmlp_fast_shape(input_dim, output_dim, hidden_dim, num_layers, activation, output_activation)) {
+        int rg = ffmlp_generic_check("ffmlp_inference", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+        if (rg != NGP_OK) return rg;
+        if (B == 0) return NGP_OK;
+        NGP_REQUIRE(inputs && weights && outputs && inference_buffer, "ffmlp_inference: null pointer (the layer-by-layer path needs the inference buffer)");
+        rg = ffmlp_generic_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, inference_buffer, outputs, (hipStream_t)stream);
+        if (rg != NGP_OK) return rg;
+        NGP_CHECK_LAUNCH("ffmlp_inference");
+        return NGP_OK;
+    }
     (void)inference_buffer;                            // activations never leave registers
     int rc = ffmlp_check("ffmlp_inference", inputs, weights, outputs, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NGP_OK) return rc;

@@ -13,6 +13,7 @@
 //   k_ffmlp_bwd_cast   workspace f32 -> grad_weights f16 (the reference's dtype).
 // The reference accumulates these GEMMs in half (cutlass_matmul.h:467-468); f32 accumulation is strictly more accurate.
 #include "ngp_mlp.h"
+#include "ngp_ffmlp_generic.h"
 
 // A fragment of W^T for output tile t (rows = input index i), k-step c (k = output index o), permuted k order.
 // W is row-major [n_out][ld]; rows o >= n_out read as zero (the 16-wide last layer padded to K = 32).
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void k_ffmlp_bwd_cast(const float* __restrict_
 static uint32_t ffmlp_nparams(uint32_t in, uint32_t out, uint32_t hid, uint32_t nl) { return hid * (in + hid * (nl - 1) + out); }
 
 extern "C" size_t ngp_ffmlp_backward_workspace(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers) {
-    return sizeof(float) * (size_t)ffmlp_nparams(input_dim, output_dim, hidden_dim, num_layers);
+    // (the layer-by-layer path also keeps transposed copies of the weights there)
+    return ffmlp_generic_backward_workspace(input_dim, output_dim, hidden_dim, num_layers);
 }
 
 template <int NHID, int INT>
@@ -223,6 +225,15 @@ extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const vo
                                   uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                                   uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
                                   void* grad_inputs, void* grad_weights, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ffmlp_fast_shape(input_dim, output_dim, hidden_dim, num_layers, activation, output_activation)) {
+        int rg = ffmlp_generic_check("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+        if (rg != NGP_OK) return rg;
+        rg = ffmlp_generic_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, calc_grad_inputs,
+                                    backward_buffer, grad_inputs, grad_weights, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rg != NGP_OK) return rg;
+        NGP_CHECK_LAUNCH("ffmlp_backward");
+        return NGP_OK;
+    }
     NGP_REQUIRE(hidden_dim == 64 && output_dim == 16, "ffmlp_backward: hidden_dim must be 64 and output_dim the padded 16");
     NGP_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= 64, "ffmlp_backward: input_dim must be 16, 32, 48 or 64");
     NGP_REQUIRE(num_layers >= 2 && num_layers <= 4, "ffmlp_backward: num_layers must be 2, 3 or 4");

@@ -38,8 +38,12 @@ class _ffmlp_forward(Function):
             ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
             ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
         else:
+            # the register-resident kernels (width 64, ReLU, 2-4 layers, input_dim <= 64) keep their activations in registers; every other shape
+            # runs layer by layer and needs the reference's inference buffer (ffmlp.py:40-41)
+            fast = hidden_dim == 64 and activation == 0 and output_activation == 6 and 2 <= num_layers <= 4 and input_dim <= 64
+            buf = None if fast else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             _hip.check(L.ngp_ffmlp_inference(_hip.ptr(inputs), _hip.ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
-                                             activation, output_activation, None, _hip.ptr(outputs), _hip.stream()),
+                                             activation, output_activation, _hip.ptr(buf), _hip.ptr(outputs), _hip.stream()),
                        "ffmlp_inference")
         return outputs
 
@@ -90,14 +94,14 @@ class FFMLP(nn.Module):
         self.output_activation = convert_activation("none")
         self.tensorcore_width = 16
 
-        # The reference's dispatch also lists widths 16/32/128/256 and five more activations (ffmlp.cu:653-657,691-695, ffmlp.py:89-96);
-        # none of its models uses them (nerf/network_ff.py:31-49: 64 wide, ReLU).  libngp_hip implements the 64-wide ReLU networks
-        # and refuses the rest (csrc/ffmlp.hip: ffmlp_check) -- refuse here too, at construction, instead of at the first forward.
-        assert hidden_dim == 64, f"FFMLP (gfx950) supports hidden_dim 64 only (the reference lists [16, 32, 64, 128, 256]), but got {hidden_dim}"
-        assert input_dim > 0 and input_dim % 16 == 0 and input_dim <= 64, f"FFMLP (gfx950) input_dim should be 16, 32, 48 or 64, but got {input_dim}"
+        # the reference's own limits (ffmlp.py:110-113); libngp_hip runs width 64 / ReLU / 2-4 layers / input_dim <= 64 (every model of the
+        # reference) on register-resident kernels and everything else layer by layer (csrc/ffmlp_generic.hip)
+        assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
+        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
+        assert input_dim <= 256, f"FFMLP (gfx950) input_dim is limited to 256, but got {input_dim}"
         assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
-        assert 2 <= num_layers <= 4, f"FFMLP (gfx950) num_layers should be 2, 3 or 4 (3 to 5 matmuls), but got {num_layers}"
-        assert self.activation == 0, f"FFMLP (gfx950) supports the ReLU hidden activation only, but got {activation!r}"
+        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
+        assert num_layers <= 16, f"FFMLP (gfx950) num_layers is limited to 16, but got {num_layers}"
 
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)

@@ -776,9 +776,33 @@ O_API void o_grid_encode_backward(const void* grad, const float* inputs, const v
  * Products of two halves are exact in binary32; sums are accumulated here in
  * double and rounded once to half per layer.  (The reference accumulates in
  * half inside WMMA, the HIP kernel in binary32 inside MFMA: see DESIGN.md.) */
-O_API void o_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
-                           uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
-                           uint16_t* forward_buffer, uint16_t* outputs) {
+/* hidden activations of ffmlp/src/utils.h:423-470, applied to the HALF pre-activation (the reference's WMMA accumulator is a half fragment) */
+static float o_ffmlp_act(uint32_t act, float x) {
+    switch (act) {
+        case 0: return x > 0 ? x : 0;                                   /* ReLU */
+        case 1: return expf(x);                                          /* Exponential */
+        case 2: return sinf(x);                                          /* Sine */
+        case 3: return 1.0f / (1.0f + expf(-x));                         /* Sigmoid (logistic) */
+        case 4: { const float y = x * 10.0f; return 0.5f * (y + sqrtf(y * y + 4.0f)) / 10.0f; }   /* Squareplus, K_ACT = 10 */
+        case 5: return logf(expf(x * 10.0f) + 1.0f) / 10.0f;             /* Softplus */
+        default: return x;                                               /* None */
+    }
+}
+/* utils.h:536-590: gradient times the derivative written through the forward OUTPUT y; every product is a half product there */
+static float o_ffmlp_act_backward(uint32_t act, float g, float y) {
+    switch (act) {
+        case 0: return y > 0 ? g : 0.0f;
+        case 1: return h2f(f2h(g * y));
+        case 3: return h2f(f2h(g * h2f(f2h(y * h2f(f2h(1.0f - y))))));
+        case 4: { const float t = y * 10.0f; return h2f(f2h(g * h2f(f2h(t * t / (t * t + 1.0f))))); }
+        case 5: return h2f(f2h(g * h2f(f2h(1.0f - expf(-y * 10.0f)))));
+        default: return g;                                               /* None; Sine has no backward in the reference (utils.h:552-556) */
+    }
+}
+
+O_API void o_ffmlp_forward_act(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
+                               uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                               uint16_t* forward_buffer, uint16_t* outputs) {
     const uint32_t n_mat = num_layers + 1;
     const uint64_t nw = (uint64_t)hidden_dim * input_dim + (uint64_t)(num_layers - 1) * hidden_dim * hidden_dim + (uint64_t)output_dim * hidden_dim;
     float* wf = (float*)malloc(sizeof(float) * nw);
@@ -797,8 +821,8 @@ O_API void o_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint
                 for (uint32_t o = 0; o < odim; o++) {
                     double acc = 0;
                     for (uint32_t k = 0; k < kdim; k++) acc += (double)(a[k] * w[(uint64_t)o * kdim + k]);
-                    float v = (float)acc;
-                    if (m != n_mat - 1) v = v > 0 ? v : 0;         /* ReLU on hidden layers */
+                    float v = h2f(f2h((float)acc));                /* the half pre-activation */
+                    if (m != n_mat - 1) v = o_ffmlp_act(activation, v);   /* hidden layers; the output layer has no activation (ffmlp.py:108) */
                     c[o] = h2f(f2h(v));
                 }
                 if (m != n_mat - 1) {
@@ -817,6 +841,11 @@ O_API void o_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint
     }
     free(wf);
 }
+O_API void o_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
+                           uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                           uint16_t* forward_buffer, uint16_t* outputs) {
+    o_ffmlp_forward_act(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, 0u, forward_buffer, outputs);
+}
 
 /* Backward, semantics of ffmlp.cu:410-518 (activation gradients) and :749-895
  * (weight-gradient GEMMs).  Outputs in binary32 (the reference rounds them to
@@ -825,10 +854,10 @@ O_API void o_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint
  *   backward_buffer[k+1] = (bwd[k] . W_hid[n-1-k]) * relu'(fwd[num_layers-2-k])   (each rounded to half)
  *   dW_last = grad^T fwd[last] ; dW_hid[i] = bwd^T fwd ; dW_in = bwd[last]^T inputs
  *   grad_inputs = bwd[last] . W_in */
-O_API void o_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
-                            const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
-                            uint32_t hidden_dim, uint32_t num_layers, int calc_grad_inputs,
-                            uint16_t* backward_buffer, float* grad_inputs, float* grad_weights) {
+O_API void o_ffmlp_backward_act(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
+                                const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, int calc_grad_inputs,
+                                uint16_t* backward_buffer, float* grad_inputs, float* grad_weights) {
     const uint64_t W = hidden_dim;
     const uint64_t off_hidden = W * input_dim;
     const uint64_t off_last = off_hidden + (uint64_t)(num_layers - 1) * W * W;
@@ -847,7 +876,7 @@ O_API void o_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const 
             for (uint32_t o = 0; o < output_dim; o++)
                 acc += (double)(h2f(grad[(uint64_t)b * output_dim + o]) * wf[off_last + (uint64_t)o * W + j]);
             const float f = h2f(forward_buffer[(uint64_t)(num_layers - 1) * B * W + (uint64_t)b * W + j]);
-            cur[j] = h2f(f2h(f > 0 ? (float)acc : 0.0f));
+            cur[j] = h2f(f2h(o_ffmlp_act_backward(activation, h2f(f2h((float)acc)), f)));
             backward_buffer[(uint64_t)b * W + j] = f2h(cur[j]);
         }
         for (uint32_t k = 0; k + 1 < num_layers; k++) {
@@ -856,7 +885,7 @@ O_API void o_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const 
                 double acc = 0;
                 for (uint32_t o = 0; o < hidden_dim; o++) acc += (double)(cur[o] * wm[(uint64_t)o * W + j]);
                 const float f = h2f(forward_buffer[(uint64_t)(num_layers - 2 - k) * B * W + (uint64_t)b * W + j]);
-                nxt[j] = h2f(f2h(f > 0 ? (float)acc : 0.0f));
+                nxt[j] = h2f(f2h(o_ffmlp_act_backward(activation, h2f(f2h((float)acc)), f)));
                 backward_buffer[(uint64_t)(k + 1) * B * W + (uint64_t)b * W + j] = f2h(nxt[j]);
             }
             memcpy(cur, nxt, sizeof(float) * hidden_dim);
@@ -895,6 +924,13 @@ O_API void o_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const 
     }
     for (uint64_t i = 0; i < nw; i++) grad_weights[i] = (float)gw[i];
     free(gw); free(wf);
+}
+O_API void o_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
+                            const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                            uint32_t hidden_dim, uint32_t num_layers, int calc_grad_inputs,
+                            uint16_t* backward_buffer, float* grad_inputs, float* grad_weights) {
+    o_ffmlp_backward_act(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, 0u, calc_grad_inputs,
+                         backward_buffer, grad_inputs, grad_weights);
 }
 
 /* ------------------------------------------------------------------ */

@@ -309,20 +309,21 @@ def ffmlp_num_params(input_dim, output_dim_padded, hidden_dim, num_layers):
     return hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + output_dim_padded)
 
 
-def ffmlp_forward(inputs, weights, input_dim, output_dim, hidden_dim, num_layers, save=False):
-    """inputs [B,in] float16, weights flat float16. Returns (outputs [B,out] f16, forward_buffer or None)."""
+def ffmlp_forward(inputs, weights, input_dim, output_dim, hidden_dim, num_layers, save=False, activation=0):
+    """inputs [B,in] float16, weights flat float16. Returns (outputs [B,out] f16, forward_buffer or None).
+    activation: the hidden activation code of ffmlp.py:89-96 (0 relu, 1 exponential, 2 sine, 3 sigmoid, 4 squareplus, 5 softplus, 6 none)."""
     x = np.ascontiguousarray(inputs, dtype=np.float16)
     w = np.ascontiguousarray(weights, dtype=np.float16)
     B = x.shape[0]
     out = np.empty((B, output_dim), np.float16)
     fb = np.empty((num_layers, B, hidden_dim), np.float16) if save else None
-    lib().o_ffmlp_forward(_p(x), _p(w), c_u32(B), c_u32(input_dim), c_u32(output_dim), c_u32(hidden_dim),
-                          c_u32(num_layers), _p(fb), _p(out))
+    lib().o_ffmlp_forward_act(_p(x), _p(w), c_u32(B), c_u32(input_dim), c_u32(output_dim), c_u32(hidden_dim),
+                              c_u32(num_layers), c_u32(activation), _p(fb), _p(out))
     return out, fb
 
 
 def ffmlp_backward(grad, inputs, weights, forward_buffer, input_dim, output_dim, hidden_dim, num_layers,
-                   calc_grad_inputs=False):
+                   calc_grad_inputs=False, activation=0):
     """Returns (grad_weights float32 flat, grad_inputs float32 [B,in] or None, backward_buffer f16)."""
     g = np.ascontiguousarray(grad, dtype=np.float16)
     x = np.ascontiguousarray(inputs, dtype=np.float16)
@@ -332,6 +333,6 @@ def ffmlp_backward(grad, inputs, weights, forward_buffer, input_dim, output_dim,
     bb = np.zeros((num_layers, B, hidden_dim), np.float16)
     gi = np.zeros((B, input_dim), np.float32) if calc_grad_inputs else None
     gw = np.zeros(w.shape, np.float32)
-    lib().o_ffmlp_backward(_p(g), _p(x), _p(w), _p(fb), c_u32(B), c_u32(input_dim), c_u32(output_dim), c_u32(hidden_dim),
-                           c_u32(num_layers), c_i32(int(calc_grad_inputs)), _p(bb), _p(gi), _p(gw))
+    lib().o_ffmlp_backward_act(_p(g), _p(x), _p(w), _p(fb), c_u32(B), c_u32(input_dim), c_u32(output_dim), c_u32(hidden_dim),
+                               c_u32(num_layers), c_u32(activation), c_i32(int(calc_grad_inputs)), _p(bb), _p(gi), _p(gw))
     return gw, gi, bb

@@ -90,9 +90,14 @@ def test_grid_encoder_level_table_and_ffmlp_layout():
         FFMLP(31, 16, 64, 2)
     with pytest.raises(AssertionError):
         FFMLP(32, 17, 64, 2)
-    # what the library refuses (csrc/ffmlp.hip: ffmlp_check) the wrapper refuses at construction: widths other than 64,
-    # activations other than ReLU, depths outside 2..4 -- the reference lists them (ffmlp.cu:653-657) but no model of it uses them
-    for bad in (dict(hidden_dim=128), dict(hidden_dim=32), dict(num_layers=5), dict(activation="sigmoid"), dict(input_dim=80)):
+    # the reference's own limits (ffmlp.py:110-113); every shape inside them is accepted (width 64 / ReLU on the register-resident kernels,
+    # the rest layer by layer: csrc/ffmlp_generic.hip)
+    for ok in (dict(hidden_dim=128), dict(hidden_dim=16), dict(num_layers=5), dict(activation="sigmoid"), dict(input_dim=80)):
+        kw = dict(input_dim=32, output_dim=16, hidden_dim=64, num_layers=2)
+        kw.update(ok)
+        net = FFMLP(**kw)
+        assert net.weights.numel() == kw["hidden_dim"] * (kw["input_dim"] + kw["hidden_dim"] * (kw["num_layers"] - 1) + 16)
+    for bad in (dict(hidden_dim=96), dict(hidden_dim=512), dict(num_layers=1), dict(input_dim=40)):
         kw = dict(input_dim=32, output_dim=16, hidden_dim=64, num_layers=2)
         kw.update(bad)
         with pytest.raises(AssertionError):

@@ -80,10 +80,13 @@ def test_ffmlp_module_pads_like_reference(oracle, dev):
 
 
 def test_ffmlp_rejects_unsupported(dev):
+    """what the reference's module refuses too (ffmlp.cu:659, ffmlp.py:110-113): a width outside [16, 32, 64, 128, 256], an output activation"""
     import ngp_hip
-    z = torch.zeros(4096, dtype=torch.float16, device=dev)
-    rc = ngp_hip.lib().ngp_ffmlp_inference(ngp_hip.ptr(z), ngp_hip.ptr(z), 16, 32, 16, 128, 2, 0, 6, None, ngp_hip.ptr(z), ngp_hip.stream())
+    z = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
+    rc = ngp_hip.lib().ngp_ffmlp_inference(ngp_hip.ptr(z), ngp_hip.ptr(z), 16, 32, 16, 96, 2, 0, 6, ngp_hip.ptr(z), ngp_hip.ptr(z), ngp_hip.stream())
     assert rc == -1 and b"hidden_dim" in ngp_hip.lib().ngp_last_error()
+    rc = ngp_hip.lib().ngp_ffmlp_inference(ngp_hip.ptr(z), ngp_hip.ptr(z), 16, 32, 16, 64, 2, 0, 3, ngp_hip.ptr(z), ngp_hip.ptr(z), ngp_hip.stream())
+    assert rc == -1 and b"output activation" in ngp_hip.lib().ngp_last_error()
 
 
 def run_hip_backward(dev, g, x, w, fb, input_dim, num_layers, calc):
