@@ -28,7 +28,7 @@ def test_no_single_rounding_conversions_in_the_shipped_kernels(tmp_path):
     this checks the optimised ISA of every kernel file for the instruction."""
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(ROOT, "nerf-navigation_amd", "csrc")
-    files = ["raymarching", "gridencoder", "shencoder", "freqencoder", "ffmlp", "ffmlp_backward", "render_fused", "field_train"]
+    files = ["raymarching", "gridencoder", "shencoder", "freqencoder", "ffmlp", "ffmlp_backward", "ffmlp_generic", "render_fused", "field_train"]
     flags = [f for f in FLAGS if f not in ("-O1", "-c", "-Werror")] + ["-O3", "-S"]      # (-S leaves hipcc's --hip-link unused: a warning)
 
     def isa(name):
