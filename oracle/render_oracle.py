@@ -17,6 +17,22 @@ from . import ngp_oracle as O
 from . import sh_oracle
 
 
+_HALF_CACHE = {}
+
+
+def _half_params(model):
+    """the float16 copies autocast makes of the table and the weights on every forward (grid.py:38-39, ffmlp.py cast_inputs): the values do not
+    depend on when they are made, so the checker makes them once per model dict (they were 45 % of a frame's time when made per call)"""
+    key = id(model)
+    hit = _HALF_CACHE.get(key)
+    if hit is None or hit[0] is not model["embeddings"]:
+        hit = (model["embeddings"], model["embeddings"].astype(np.float16), model["sigma_weights"].astype(np.float16),
+               model["color_weights"].astype(np.float16))
+        _HALF_CACHE.clear()
+        _HALF_CACHE[key] = hit
+    return hit[1], hit[2], hit[3]
+
+
 def field_forward(model, xyzs, dirs, density_scale=1.0):
     """model: dict from workload.make_model (float32 params).  Returns sigma [M] f32 (times density_scale), rgb [M,3] f32."""
     bound = np.float32(model["bound"])
@@ -26,20 +42,20 @@ def field_forward(model, xyzs, dirs, density_scale=1.0):
     # gridencoder/grid.py:144, `(inputs + bound) / (2 * bound)`, as torch evaluates it on the reference's GPU: the product with the binary32
     # reciprocal of the host scalar (ATen BinaryDivTrueKernel.cu); the exact quotient when 2 * bound is a power of two
     x01 = ((x + np.float32(bound)) * (np.float32(1) / (np.float32(2) * np.float32(bound)))).astype(np.float32)
-    emb = model["embeddings"].astype(np.float16)                                        # grid.py:38-39 (autocast)
+    emb, w_sigma, w_color = _half_params(model)                                         # grid.py:38-39 (autocast)
     feats, _ = O.grid_encode_forward(x01, emb, model["offsets"], model["per_level_scale"], 16, False, 0, False)
     feats = np.ascontiguousarray(feats.transpose(1, 0, 2).reshape(M, 32))               # grid.py:52
     pad = (-M) % 16
     if pad:
         feats = np.concatenate([feats, np.zeros((pad, 32), np.float16)])
-    h, _ = O.ffmlp_forward(feats, model["sigma_weights"].astype(np.float16), 32, 16, 64, 2)
+    h, _ = O.ffmlp_forward(feats, w_sigma, 32, 16, 64, 2)
     h = h[:M]
     sigma = O.expf(h[:, 0].astype(np.float32)) * np.float32(density_scale)              # trunc_exp, float32
     sh = sh_oracle.sh_encode(d, 4).astype(np.float32)                                   # SHEncoder output is float32
     cin = np.concatenate([sh.astype(np.float16), h[:, 1:], np.zeros((M, 1), np.float16)], axis=1)   # network_ff.py:67-68
     if pad:
         cin = np.concatenate([cin, np.zeros((pad, 32), np.float16)])
-    c, _ = O.ffmlp_forward(np.ascontiguousarray(cin), model["color_weights"].astype(np.float16), 32, 16, 64, 3)
+    c, _ = O.ffmlp_forward(np.ascontiguousarray(cin), w_color, 32, 16, 64, 3)
     c = c[:M, :3].astype(np.float32)
     rgb = (np.float32(1) / (np.float32(1) + O.expf(-c))).astype(np.float16).astype(np.float32)   # sigmoid on a half tensor
     return sigma.astype(np.float32), rgb
