@@ -140,7 +140,7 @@ def bench_train(args, rank, world, dev, W, teacher):
     elapsed, loss, points, scatter_ms, calls = timed_phase(k0, args.steps)  # steady state
     rays_all, t_max = sharding.reduce_throughput(n_rays * args.steps, elapsed, dev)
     if rank == 0:
-        def roof(pts, ms):
+        def roof(pts, ms, profiled_phase=False):
             if not ms:
                 return None
             a = SCATTER_BYTES_PER_POINT * pts / (ms * 1e-3) / 1e9
@@ -154,6 +154,9 @@ def bench_train(args, rank, world, dev, W, teacher):
             if c is not None and c.get("WRITE_SIZE"):
                 r["profile"] = info["profile"]
                 r["profiled_requests_per_launch"] = c["WRITE_SIZE"] * 1024.0 / 64.0
+                if profiled_phase:                 # profiles/r14_train was collected on the early grid: its bytes belong to the warm-up phase's launches
+                    r["traffic"] = (c["WRITE_SIZE"] + c.get("FETCH_SIZE", 0.0)) * 1024.0
+                    r["traffic_unit"] = "bytes per launch, fabric side (every atomic request is a 32-byte write; L2 hit rate 0.007)"
             return r
         print(json.dumps({
             "metric": "training rays/sec (4096-ray steps, FFMLP field under autocast, Adam, grid refresh every 16 steps)",
@@ -165,7 +168,7 @@ def bench_train(args, rank, world, dev, W, teacher):
                        "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": loss},
             "roofline": roof(points, scatter_ms),
             "warmup_phase": {"ms_per_step": 1e3 * warm[0] / args.steps, "points_per_step": warm[2], "loss": warm[1],
-                             "roofline": roof(warm[2], warm[3])}}))
+                             "roofline": roof(warm[2], warm[3], profiled_phase=True)}}))
     if world > 1:
         dist.destroy_process_group()
 
