@@ -72,6 +72,14 @@ static inline float o_expf(float x) {
     return u.f;
 }
 
+/* OpenMP team size of the checker's parallel loops (the runtime is usually loaded before this library, so OMP_NUM_THREADS set later is not read) */
+#ifdef _OPENMP
+#include <omp.h>
+O_API int o_set_threads(int n) { const int before = omp_get_max_threads(); if (n > 0) omp_set_num_threads(n); return before; }
+#else
+O_API int o_set_threads(int n) { (void)n; return 1; }
+#endif
+
 O_API void o_expf_array(const float* x, float* y, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) y[i] = o_expf(x[i]);
 }

@@ -38,6 +38,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """team size of the C loops' OpenMP regions; returns the previous maximum"""
+    return int(lib().o_set_threads(ctypes.c_int(int(n))))
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
