@@ -82,6 +82,12 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
 // Coherence knobs (round 2; same images, tools/ab_variants.sh and tools/ab_trained.sh: ms per 800x800 frame of the hand-set model | G ray-samples/s on
 // a model fitted for 2,000 and for 8,000 steps).  Lane l of a wave gathers for the samples of ray l; what the 64 addresses of one gather instruction
 // share (cells of the coarse and middle levels, i.e. cache lines) decides how fast a CU's texture path and L1 turn a tile around.
+#ifndef RV_BANDS
+#define RV_BANDS 32u              // image bands (ray queues): a multiple of 8, at most 32 (queue words 32..63 of the workspace header).  XCD x works through bands
+                                  // x, x + 8, x + 16, x + 24: with 8 thick bands the XCDs whose band was sky or ground finished early and queued behind one another
+                                  // on their neighbour's; thin interleaved bands give every XCD a fair sample of the image and keep its rays together.
+                                  // 8: 3.47-3.56 | 7.8-8.0    16: 3.40 | 7.4    32: 3.35-3.38 | 7.7    one global queue: 3.29-3.42 | 7.6-7.9, with 2x the fabric traffic
+#endif
 #ifndef RV_REFILL_MIN
 #define RV_REFILL_MIN 64       // a wave draws new rays only when this many of its lanes are free.  64 = a whole 8x8 pixel tile at a time: the rays of a wave stay
 #endif                         // neighbours for life (1 = any free lane takes the next ray of the queue at once; after a few rounds a wave holds rays of many
@@ -636,13 +642,12 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 const uint32_t cnt = (uint32_t)__popcll(need);
                 uint32_t base = 0;
 #if RV_XCD_QUEUES
-                // Queue q holds the rays of image band q (tiles [T q / 8, T (q + 1) / 8) of 64 rays): the workgroups of one XCD
-                // start on the same band, so that the table lines neighbouring rays share are fetched into ONE L2 and
-                // not into eight.  A wave that finds its queue empty moves on to the next one (stealing keeps the load
-                // balanced; the lanes left without a ray wait one round).
+                // Queue q holds the rays of image band q (tiles [T q / RV_BANDS, T (q + 1) / RV_BANDS) of 64 rays): the workgroups of one XCD
+                // work on the same band, so that the table lines neighbouring rays share are fetched into ONE L2 and
+                // not into eight.  A wave that finds its queue empty moves on to its XCD's next band, then to the other XCDs'.
                 const uint32_t n_tiles64 = (F.N + 63u) >> 6;
-                const uint32_t q_lo = (uint32_t)(((unsigned long long)n_tiles64 * rv_q) >> 3) << 6;
-                uint32_t q_hi = (uint32_t)(((unsigned long long)n_tiles64 * (rv_q + 1u)) >> 3) << 6;
+                const uint32_t q_lo = (uint32_t)(((unsigned long long)n_tiles64 * rv_q) / RV_BANDS) << 6;
+                uint32_t q_hi = (uint32_t)(((unsigned long long)n_tiles64 * (rv_q + 1u)) / RV_BANDS) << 6;
                 q_hi = q_hi < F.N ? q_hi : F.N;
                 if (lane == 0) base = atomicAdd(F.queue + 32 + rv_q, cnt);
                 base = __shfl(base, 0, 64) + q_lo;
@@ -681,8 +686,11 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 }
 #if RV_XCD_QUEUES
                 if (base + cnt >= q_hi) {                  // this queue has run dry: move on, until all eight have been seen
-                    rv_q = (rv_q + 1u) & 7u;
-                    if (++rv_q_seen == 8u) exhausted = true;
+                    // XCD x owns bands x, x + 8, x + 16, ...: thin bands spread over the whole image, so that every XCD gets a fair sample of cheap and
+                    // expensive rows; when its own are done it goes on with the next XCD's
+                    rv_q += 8u;
+                    if (rv_q >= RV_BANDS) rv_q = (rv_q + 1u) & 7u;
+                    if (++rv_q_seen == RV_BANDS) exhausted = true;
                 }
 #else
                 if (base + cnt >= F.N) exhausted = true;
