@@ -6,11 +6,11 @@ import torch
 
 class PSNRMeter:
     def __init__(self):
-        self.V = 0.0
+        self.V = 0
         self.N = 0
 
     def clear(self):
-        self.V, self.N = 0.0, 0
+        self.V, self.N = 0, 0
 
     @staticmethod
     def _host(a):
@@ -19,7 +19,9 @@ class PSNRMeter:
     def update(self, preds, truths):
         """preds, truths [B, N, 3] or [B, H, W, 3] in [0, 1]: adds -10 log10(MSE) of this batch (peak value 1)."""
         p, t = self._host(preds), self._host(truths)
-        self.V += float(-10 * np.log10(np.mean((p - t) ** 2)))
+        # the reference keeps numpy's scalar types: float32 inputs give a float32 PSNR and a float32 running sum (nerf/utils.py:203-210);
+        # pinned by tests/golden/callers_tier1.npz (three updates, executed reference code)
+        self.V += -10 * np.log10(np.mean((p - t) ** 2))
         self.N += 1
 
     def measure(self):

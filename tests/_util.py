@@ -72,3 +72,16 @@ def ff_grads_as_matrices(net):
     for r, c in shapes:
         out.append(g[off:off + r * c].reshape(r, c)); off += r * c
     return out
+
+
+def ff_model_matrices(model):
+    """the flat FFMLP weights of a workload.make_model() dict as per-layer matrices (ffmlp/ffmlp.py:121-122: [64,32] + k [64,64] + [16,64]):
+    (sigma net [64,32],[64,64],[16,64]; colour net [64,32],[64,64],[64,64],[16,64])"""
+    def split(flat, n_hidden):
+        shapes = [(64, 32)] + [(64, 64)] * (n_hidden - 1) + [(16, 64)]
+        out, off = [], 0
+        for r, c in shapes:
+            out.append(np.asarray(flat[off:off + r * c], np.float32).reshape(r, c)); off += r * c
+        assert off == flat.size
+        return out
+    return split(model["sigma_weights"], 2), split(model["color_weights"], 3)

@@ -1,0 +1,425 @@
+"""Golden vectors for the caller rows (provider) produced by EXECUTING THE REFERENCE'S OWN PYTHON.
+
+Build container only (needs /root/reference); run as `python -B tests/golden/make_callers_golden.py` from the repository root.
+Writes data only: tests/golden/callers_tier1.npz, callers_run.npz, callers_run_cuda.npz, callers_grid.npz.
+
+What executes, and what does not:
+  * imported from /root/reference and run on the CPU: nerf/utils.py (get_rays :53-116, PSNRMeter :185-219), nerf/renderer.py
+    (sample_pdf :12-46, NeRFRenderer.run :125-254, run_cuda :257-379, mark_untrained_grid :381-442, update_extra_state :446-537),
+    nerf/provider.py (nerf_matrix_to_ngp :19-27);
+  * the third-party modules those files import but never use on these paths and that this image lacks (cv2, trimesh, imageio,
+    tensorboardX, mcubes, torch_ema, lpips) are EMPTY placeholder modules in sys.modules;
+  * the reference's extension packages (raymarching, gridencoder, shencoder, ffmlp) are NEVER imported: they are CUDA, importing
+    them would hipify into /root/reference.  `raymarching` is a module object whose nine functions are the CPU
+    oracle's leaf ops (oracle/ngp_oracle.c, oracle/callers_oracle.py), and the abstract field methods of NeRFRenderer
+    (forward / density / color, nerf/renderer.py:103-112) are oracle.callers_oracle.DefaultField.
+  So: the CONTROL FLOW AND TENSOR ARITHMETIC OF THE CALLERS is the reference's, executed; the leaf kernels under it are the
+  oracle's (they stay "parity unpinned": the reference's CUDA cannot be built here).
+  * random numbers: get_rays / sample_pdf / run(perturb) draw from torch's global RNG -> the script records what was drawn
+    (the product takes the same numbers as inputs).  update_extra_state draws `rand_like` / `randint`: those two functions are
+    replaced, for the duration of the call, by readers of the pcg32 streams the native op uses (oracle.callers_oracle
+    .grid_update_randoms), so one fixture serves the oracle and the HIP op.
+  * nothing is written under /root/reference (python -B / sys.dont_write_bytecode).
+The model is ngp.workload.make_model(0) (numpy, seeded), rebuilt by the tests from the same seed: the files hold rays, poses,
+random numbers and the reference's outputs only.
+"""
+import importlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+importlib.import_module("nerf-navigation_amd")          # puts ngp/ on the path (workload is numpy only)
+from ngp import workload as W  # noqa: E402
+from oracle import callers_oracle as CO  # noqa: E402
+from oracle import ngp_oracle as O  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _util import ff_model_matrices  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# placeholders for absent third-party modules, and the `raymarching` module over the oracle's leaf ops
+# ------------------------------------------------------------------------------------------------------------------------
+def _install_placeholders():
+    for name in ("cv2", "trimesh", "imageio", "tensorboardX", "mcubes", "torch_ema", "lpips"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["cv2"].transform = None                               # `from cv2 import transform` (nerf/provider.py:5)
+    sys.modules["torch_ema"].ExponentialMovingAverage = object       # `from torch_ema import ExponentialMovingAverage`
+
+
+def _np(t):
+    return t.detach().contiguous().numpy()
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+MARCH_LOG = []                                                       # (n_alive, n_step, live samples) per march_rays call
+
+
+def _oracle_raymarching():
+    """module `raymarching` with the wrapper-level signatures of raymarching/raymarching.py over oracle leaf ops"""
+    m = types.ModuleType("raymarching")
+
+    def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
+        n, f = O.near_far_from_aabb(_np(rays_o), _np(rays_d), _np(aabb), min_near)
+        return _t(n), _t(f)
+
+    def sph_from_ray(rays_o, rays_d, radius):
+        return _t(O.sph_from_ray(_np(rays_o), _np(rays_d), radius))
+
+    def morton3D(coords):
+        return _t(O.morton3D(_np(coords.int())))
+
+    def morton3D_invert(indices):
+        return _t(O.morton3D_invert(_np(indices.int())))
+
+    def packbits(grid, thresh, bitfield=None):
+        return _t(O.packbits(_np(grid), thresh))
+
+    def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
+                         align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        counter = step_counter.numpy()                               # a contiguous int32 row of step_counter: updated in place
+        assert counter.dtype == np.int32 and counter.flags["C_CONTIGUOUS"]
+        x, d, l, r = O.march_rays_train(_np(rays_o), _np(rays_d), bound, _np(density_bitfield), C, H, _np(nears), _np(fars), counter,
+                                        mean_count, perturb, align, force_all_rays, dt_gamma, max_steps)
+        return _t(x), _t(d), _t(l), _t(r)
+
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1, perturb=False,
+                   dt_gamma=0, max_steps=1024):
+        x, d, l = O.march_rays(n_alive, n_step, _np(rays_alive), _np(rays_t), _np(rays_o), _np(rays_d), bound, _np(density_bitfield), C, H,
+                               _np(near), _np(far), align, perturb, dt_gamma, max_steps)
+        MARCH_LOG.append((int(n_alive), int(n_step), int((l[:, 0] > 0).sum())))
+        return _t(x), _t(d), _t(l)
+
+    def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+        for a in (rays_alive, rays_t, weights_sum, depth, image):
+            assert a.is_contiguous()
+        O.composite_rays(n_alive, n_step, rays_alive.numpy(), rays_t.numpy(), _np(sigmas.float()), _np(rgbs.float()), _np(deltas),
+                         weights_sum.numpy(), depth.numpy(), image.numpy())            # in place, like the reference's op
+        return tuple()
+
+    for fn in (near_far_from_aabb, sph_from_ray, morton3D, morton3D_invert, packbits, march_rays_train, march_rays, composite_rays):
+        setattr(m, fn.__name__, fn)
+    m.composite_rays_train = CO.composite_rays_train
+    return m
+
+
+def import_reference():
+    _install_placeholders()
+    sys.modules["raymarching"] = _oracle_raymarching()
+    sys.path.insert(0, REF)
+    import nerf.provider as P
+    import nerf.renderer as R
+    import nerf.utils as U
+    assert U.__file__.startswith(REF) and R.__file__.startswith(REF) and P.__file__.startswith(REF)
+    return U, R, P
+
+
+def make_renderer(R, field, **kw):
+    class OracleFieldRenderer(R.NeRFRenderer):                       # the reference's class; only its abstract methods are filled in
+        def forward(self, x, d):
+            return field(x, d)
+
+        def density(self, x):
+            return field.density(x)
+
+        def color(self, x, d, mask=None, **kwargs):
+            return field.color(x, d, mask=mask, **kwargs)
+
+    return OracleFieldRenderer(**kw)
+
+
+def small_grid(ren, H):
+    """the reference hard-codes grid_size = 128 (nerf/renderer.py:74); the grid fixtures use a smaller H so that they stay small"""
+    ren.grid_size = H
+    ren.density_grid = torch.zeros([ren.cascade, H ** 3])
+    ren.density_bitfield = torch.zeros(ren.cascade * H ** 3 // 8, dtype=torch.uint8)
+    return ren
+
+
+class Capture:
+    """record / replace the draws of torch.rand, rand_like, randint while the reference code runs"""
+
+    def __init__(self, **replacements):
+        self.repl, self.saved, self.log = replacements, {}, []
+
+    def __enter__(self):
+        for name in ("rand", "rand_like", "randint", "multinomial"):
+            orig = getattr(torch, name)
+            self.saved[name] = orig
+
+            def wrapped(*a, _orig=orig, _name=name, **k):
+                out = self.repl[_name](*a, **k) if _name in self.repl else _orig(*a, **k)
+                self.log.append((_name, out.clone()))
+                return out
+            setattr(torch, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self.saved.items():
+            setattr(torch, name, orig)
+        return False
+
+    def drawn(self, name):
+        return [v for n, v in self.log if n == name]
+
+
+def oracle_field():
+    model = W.make_model(0)
+    sw, cw = ff_model_matrices(model)
+    return model, CO.DefaultField(model["embeddings"], model["offsets"], model["per_level_scale"], sw, cw, model["bound"], ff_layout=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def tier1(U, R, P):
+    out = {}
+    # get_rays: two cameras, a non-square image, off-centre principal point
+    poses = np.stack([W.orbit_pose(1), W.orbit_pose(5, radius=2.1, height=-0.3)])
+    intr = np.array([41.5, 39.25, 15.75, 12.5], np.float32)
+    H, Wd = 24, 32
+    out["gr_poses"], out["gr_intrinsics"], out["gr_HW"] = poses, intr, np.array([H, Wd])
+    full = U.get_rays(torch.from_numpy(poses), intr, H, Wd)
+    out["gr_full_o"], out["gr_full_d"] = _np(full["rays_o"]), _np(full["rays_d"])
+    torch.manual_seed(3)
+    rnd = U.get_rays(torch.from_numpy(poses), intr, H, Wd, N=100)
+    out["gr_rand_inds"], out["gr_rand_o"], out["gr_rand_d"] = _np(rnd["inds"]), _np(rnd["rays_o"]), _np(rnd["rays_d"])
+    torch.manual_seed(4)
+    err = torch.rand(2, 128 * 128) + 0.01
+    with Capture() as cap:
+        em = U.get_rays(torch.from_numpy(poses), intr, H, Wd, N=64, error_map=err)
+    out["gr_err_map"] = _np(err)
+    out["gr_err_inds_coarse"], out["gr_err_inds"] = _np(em["inds_coarse"]), _np(em["inds"])
+    out["gr_err_u"] = np.stack([_np(v) for v in cap.drawn("rand")])                 # the two torch.rand(B, N) draws, in order
+    out["gr_err_o"], out["gr_err_d"] = _np(em["rays_o"]), _np(em["rays_d"])
+
+    # PSNRMeter: three updates of different shapes
+    rng = np.random.default_rng(5)
+    meter = U.PSNRMeter()
+    for k, shape in enumerate([(1, 50, 3), (1, 8, 8, 3), (2, 30, 3)]):
+        t = rng.uniform(0, 1, shape).astype(np.float32)
+        p = np.clip(t + rng.normal(scale=0.02 * (k + 1), size=shape), 0, 1).astype(np.float32)
+        meter.update(torch.from_numpy(p), torch.from_numpy(t))
+        out[f"psnr_pred{k}"], out[f"psnr_truth{k}"] = p, t
+        out[f"psnr_after{k}"] = np.float64(meter.measure())
+    out["psnr_report"] = np.array(meter.report())
+
+    # sample_pdf: det and random; includes an all-zero weight row and a one-hot row
+    B, T, n = 6, 17, 24
+    bins = np.sort(rng.uniform(0.2, 3.0, (B, T)).astype(np.float32), axis=1)
+    wts = rng.uniform(0, 1, (B, T - 1)).astype(np.float32) ** 4
+    wts[1] = 0
+    wts[2] = 0; wts[2, 5] = 1
+    out["pdf_bins"], out["pdf_weights"] = bins, wts
+    out["pdf_det"] = _np(R.sample_pdf(torch.from_numpy(bins), torch.from_numpy(wts), n, det=True))
+    torch.manual_seed(6)
+    with Capture() as cap:
+        out["pdf_rand"] = _np(R.sample_pdf(torch.from_numpy(bins), torch.from_numpy(wts), n, det=False))
+    out["pdf_u"] = _np(cap.drawn("rand")[0])
+
+    # nerf_matrix_to_ngp
+    mats = rng.normal(size=(4, 4, 4)).astype(np.float64)
+    mats[:, 3] = [0, 0, 0, 1]
+    out["n2n_in"] = mats
+    out["n2n_default"] = np.stack([P.nerf_matrix_to_ngp(m) for m in mats])
+    out["n2n_scaled"] = np.stack([P.nerf_matrix_to_ngp(m, scale=0.8, offset=[0.1, -0.2, 0.3]) for m in mats])
+    return out
+
+
+def run_rays():
+    o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(12, 12), 12, 12)
+    # + an axis-parallel ray, a ray starting inside the box and a ray that misses it
+    eo = np.array([[-3, 0.1, 0.2], [0.1, 0.2, 0.3], [5, 5, 5]], np.float32)
+    ed = np.array([[1, 0, 0], [0.6, 0.0, -0.8], [1, 0, 0]], np.float32)
+    return np.concatenate([o, eo]), np.concatenate([d, ed])
+
+
+def tier2_run(R):
+    """NeRFRenderer.run (nerf/renderer.py:125-254): image / depth / weights_sum and d(sum(image * w) + sum(depth * v)) / d rays"""
+    model, field = oracle_field()
+    ren = make_renderer(R, field, bound=W.BOUND, cuda_ray=False, min_near=0.2, density_thresh=10).eval()
+    ro, rd = run_rays()
+    rng = np.random.default_rng(7)
+    wi = rng.uniform(0.5, 1.5, (ro.shape[0], 3)).astype(np.float32)
+    wd = rng.uniform(0.5, 1.5, ro.shape[0]).astype(np.float32)
+    out = {"rays_o": ro, "rays_d": rd, "w_image": wi, "w_depth": wd}
+    for tag, kw in (("fixed", dict(num_steps=64, upsample_steps=0)), ("upsample", dict(num_steps=48, upsample_steps=32)),
+                    ("perturb", dict(num_steps=64, upsample_steps=0, perturb=True))):
+        o = torch.from_numpy(ro)[None].clone().requires_grad_(True)
+        d = torch.from_numpy(rd)[None].clone().requires_grad_(True)
+        torch.manual_seed(8)
+        with Capture() as cap:
+            res = ren.run(o, d, bg_color=1.0, **kw)
+        hit = torch.isfinite(res["depth"][0])
+        loss = (res["image"][0] * torch.from_numpy(wi)).sum() + (res["depth"][0][hit] * torch.from_numpy(wd)[hit]).sum()
+        loss.backward()
+        out[f"{tag}_image"], out[f"{tag}_depth"], out[f"{tag}_weights_sum"] = _np(res["image"][0]), _np(res["depth"][0]), _np(res["weights_sum"])
+        out[f"{tag}_grad_o"], out[f"{tag}_grad_d"] = _np(o.grad[0]), _np(d.grad[0])
+        if kw.get("perturb"):
+            out[f"{tag}_u"] = _np(cap.drawn("rand")[0])
+        out[f"{tag}_kw"] = np.array([kw["num_steps"], kw["upsample_steps"], int(bool(kw.get("perturb")))])
+    # training-mode resampling (det=False: sample_pdf draws torch.rand)
+    ren.train()
+    torch.manual_seed(9)
+    with Capture() as cap, torch.no_grad():
+        res = ren.run(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], bg_color=1.0, num_steps=48, upsample_steps=32)
+    out["train_upsample_image"], out["train_upsample_depth"] = _np(res["image"][0]), _np(res["depth"][0])
+    out["train_upsample_u"] = _np(cap.drawn("rand")[0])
+    return out
+
+
+def table_grad_digest(g, n_keep=4096, seed=0):
+    """a 50 MB table gradient as (rows touched, l2 norm, sum, |.|-sum, values at n_keep seeded touched rows)"""
+    g = np.asarray(g, np.float64)
+    rows = np.flatnonzero(np.any(g != 0, axis=1))
+    pick = np.sort(np.random.default_rng(seed).choice(rows, size=min(n_keep, rows.size), replace=False))
+    return dict(n_rows=np.int64(rows.size), norm=np.float64(np.linalg.norm(g)), sum=np.float64(g.sum()), abs_sum=np.float64(np.abs(g).sum()),
+                rows=pick.astype(np.int64), values=g[pick].astype(np.float32))
+
+
+def tier2_run_cuda(R):
+    """NeRFRenderer.run_cuda (nerf/renderer.py:257-379), both branches, on the S-ring scene's analytic occupancy grid"""
+    model, field = oracle_field()
+    ren = make_renderer(R, field, bound=W.BOUND, cuda_ray=True, min_near=0.2, density_thresh=10)
+    grid = W.density_grid()
+    bitfield, _ = W.bitfield_from_grid(grid)
+    ren.density_grid.copy_(torch.from_numpy(grid))
+    ren.density_bitfield.copy_(torch.from_numpy(bitfield))
+    out = {}
+    # ---- inference branch: the alive-count schedule, compaction, background mix, depth normalisation
+    ro, rd = W.get_rays(W.orbit_pose(1), W.intrinsics(20, 20), 20, 20)
+    ro, rd = np.concatenate([ro, [[5, 5, 5]]]).astype(np.float32), np.concatenate([rd, [[1, 0, 0]]]).astype(np.float32)      # + a miss: depth 0/0
+    ren.eval()
+    del MARCH_LOG[:]
+    with torch.no_grad():
+        res = ren.run_cuda(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], dt_gamma=0, bg_color=1.0, perturb=False, max_steps=1024)
+    out["inf_rays_o"], out["inf_rays_d"] = ro, rd
+    out["inf_trace"] = np.array(MARCH_LOG, np.int64)
+    out["inf_image"], out["inf_depth"] = _np(res["image"][0]), _np(res["depth"][0])
+    # a second view with dt_gamma > 0 and a coloured background
+    ro2, rd2 = W.get_rays(W.orbit_pose(4), W.intrinsics(16, 16), 16, 16)
+    del MARCH_LOG[:]
+    with torch.no_grad():
+        res = ren.run_cuda(torch.from_numpy(ro2)[None], torch.from_numpy(rd2)[None], dt_gamma=1 / 128, bg_color=torch.tensor([0.2, 0.5, 0.7]),
+                           perturb=False, max_steps=1024)
+    out["inf2_rays_o"], out["inf2_rays_d"] = ro2, rd2
+    out["inf2_trace"] = np.array(MARCH_LOG, np.int64)
+    out["inf2_image"], out["inf2_depth"] = _np(res["image"][0]), _np(res["depth"][0])
+
+    # ---- training branch: counter ring, mean_count feedback, image, gradients of sum(image * w) to every parameter
+    ren.train()
+    ro, rd = W.get_rays(W.orbit_pose(2), W.intrinsics(16, 16), 16, 16)
+    rng = np.random.default_rng(10)
+    wi = rng.uniform(0.5, 1.5, (ro.shape[0], 3)).astype(np.float32)
+    out["trn_rays_o"], out["trn_rays_d"], out["trn_w_image"] = ro, rd, wi
+    for tag, kw in (("trn", dict(perturb=False)), ("trnp", dict(perturb=True))):
+        for p in field.parameters():
+            p.grad = None
+        res = ren.run_cuda(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], dt_gamma=0, bg_color=1.0, force_all_rays=False,
+                           max_steps=1024, **kw)
+        (res["image"][0] * torch.from_numpy(wi)).sum().backward()
+        out[f"{tag}_image"], out[f"{tag}_depth"], out[f"{tag}_weights_sum"] = _np(res["image"][0]), _np(res["depth"][0]), _np(res["weights_sum"])
+        out[f"{tag}_counter"] = ren.step_counter.numpy().copy()
+        out[f"{tag}_local_step"] = np.int64(ren.local_step)
+        for k, w in enumerate(field.sigma_weights):
+            out[f"{tag}_grad_sigma_w{k}"] = _np(w.grad)
+        for k, w in enumerate(field.color_weights):
+            out[f"{tag}_grad_color_w{k}"] = _np(w.grad)
+        for k, v in table_grad_digest(_np(field.embeddings.grad)).items():
+            out[f"{tag}_grad_table_{k}"] = v
+    # the mean_count feedback of update_extra_state's tail (nerf/renderer.py:534-537) and the bounded allocation it causes
+    # (raymarching/raymarching.py:196-203): third call with mean_count known
+    total = min(16, ren.local_step)
+    ren.mean_count = int(ren.step_counter[:total, 0].sum().item() / total)
+    out["trn3_mean_count"] = np.int64(ren.mean_count)
+    res = ren.run_cuda(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], dt_gamma=0, bg_color=1.0, perturb=False, max_steps=1024)
+    out["trn3_image"], out["trn3_counter"] = _np(res["image"][0].detach()), ren.step_counter.numpy().copy()
+    return out
+
+
+def tier2_grid(R, H=32, seed=0):
+    """update_extra_state (full sweep, then a partial one) and mark_untrained_grid on an H^3 grid"""
+    model, field = oracle_field()
+    ren = small_grid(make_renderer(R, field, bound=W.BOUND, cuda_ray=True, min_near=0.2, density_thresh=10), H)
+    cas = ren.cascade
+    out = {"H": np.int64(H), "seed": np.int64(seed)}
+
+    # mark_untrained_grid: five cameras close to the scene, so that part of the grid is unseen
+    poses = np.stack([W.orbit_pose(k, n=5, radius=1.2, height=0.4) for k in range(5)])
+    intr = W.intrinsics(64, 64)
+    ren.mark_untrained_grid(poses, intr, S=16)
+    out["mark_poses"], out["mark_intrinsics"] = poses, intr
+    out["mark_unseen"] = np.packbits(ren.density_grid.numpy() < 0)
+    ren.density_grid.zero_()
+
+    def replacements(rnd, partial):
+        calls = {"rand_like": 0, "randint": 0}
+        coords_mesh = None
+        if not partial:
+            ar = torch.arange(H, dtype=torch.int32)
+            xx, yy, zz = torch.meshgrid(ar, ar, ar, indexing="ij")
+            coords_mesh = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+            order = O.morton3D(coords_mesh.numpy()).astype(np.int64)
+
+        def rand_like(t, **k):
+            c = calls["rand_like"]; calls["rand_like"] += 1
+            if not partial:                                           # one call per cascade, rows in custom_meshgrid order (:460-481)
+                return _t(rnd["noise"][c][order]).to(t.dtype)
+            n_occ = t.shape[0] - rnd["noise_rand"][c].shape[0]
+            both = np.concatenate([rnd["noise_rand"][c], rnd["noise_occ"][c][:n_occ]])
+            return _t(both).to(t.dtype)
+
+        def randint(lo, hi, size, **k):
+            c = calls["randint"]; calls["randint"] += 1
+            cascade_i, which = divmod(c, 2)
+            if which == 0:                                            # coords (:494)
+                return _t(rnd["coords"][cascade_i].astype(np.int64))
+            return _t(rnd["pick"][cascade_i].astype(np.int64))        # rand_mask (:498), index into the occupied list
+        return {"rand_like": rand_like, "randint": randint}
+
+    # full sweep from an all-zero grid; two training steps are on the counter ring
+    ren.step_counter[0, 0], ren.step_counter[1, 0], ren.local_step = 1000, 1301, 2
+    rnd = CO.grid_update_randoms(seed, ren.iter_density, cas, H, partial=False)
+    with Capture(**replacements(rnd, False)):
+        ren.update_extra_state(decay=0.95, S=H)
+    out["full_grid"], out["full_bitfield"] = ren.density_grid.numpy().copy(), ren.density_bitfield.numpy().copy()
+    out["full_mean_density"], out["full_mean_count"] = np.float64(ren.mean_density), np.int64(ren.mean_count)
+
+    # partial sweep (iter_density >= 16)
+    ren.iter_density = 16
+    grid_before = ren.density_grid.numpy().copy()
+    n_occ = [(grid_before[c] > 0).sum() for c in range(cas)]
+    rnd = CO.grid_update_randoms(seed, ren.iter_density, cas, H, partial=True, n_occ=n_occ)
+    with Capture(**replacements(rnd, True)):
+        ren.update_extra_state(decay=0.95, S=H)
+    out["partial_grid"], out["partial_bitfield"] = ren.density_grid.numpy().copy(), ren.density_bitfield.numpy().copy()
+    out["partial_mean_density"] = np.float64(ren.mean_density)
+    return out
+
+
+def main():
+    U, R, P = import_reference()
+    torch.set_num_threads(8)
+    O.set_threads(8)
+    for name, fn in (("callers_tier1", lambda: tier1(U, R, P)), ("callers_run", lambda: tier2_run(R)),
+                     ("callers_run_cuda", lambda: tier2_run_cuda(R)), ("callers_grid", lambda: tier2_grid(R))):
+        data = fn()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: {len(data)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+    assert not os.path.exists(os.path.join(REF, "nerf", "__pycache__")), "bytecode was written into the reference tree"
+
+
+if __name__ == "__main__":
+    main()
