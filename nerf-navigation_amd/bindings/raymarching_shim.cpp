@@ -4,32 +4,34 @@ using namespace shim;
 
 void near_far_from_aabb(const at::Tensor rays_o, const at::Tensor rays_d, const at::Tensor aabb, const uint32_t N, const float min_near,
                         at::Tensor nears, at::Tensor fars) {
-    on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(aabb, "aabb"); on_gpu(nears, "nears"); on_gpu(fars, "fars");
+    const int64_t n = N;
+    need_f32(rays_o, "rays_o", 3 * n); need_f32(rays_d, "rays_d", 3 * n); need_f32(aabb, "aabb", 6); need_f32(nears, "nears", n); need_f32(fars, "fars", n);
     device_guard g(rays_o.device());
     ok(ngp_near_far_from_aabb(ptr<float>(rays_o), ptr<float>(rays_d), ptr<float>(aabb), N, min_near, ptr<float>(nears), ptr<float>(fars),
                               stream_of(rays_o)), "near_far_from_aabb");
 }
 
 void sph_from_ray(const at::Tensor rays_o, const at::Tensor rays_d, const float radius, const uint32_t N, at::Tensor coords) {
-    on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(coords, "coords");
+    const int64_t n = N;
+    need_f32(rays_o, "rays_o", 3 * n); need_f32(rays_d, "rays_d", 3 * n); need_f32(coords, "coords", 2 * n);
     device_guard g(rays_o.device());
     ok(ngp_sph_from_ray(ptr<float>(rays_o), ptr<float>(rays_d), radius, N, ptr<float>(coords), stream_of(rays_o)), "sph_from_ray");
 }
 
 void morton3D(const at::Tensor coords, const uint32_t N, at::Tensor indices) {
-    on_gpu(coords, "coords"); on_gpu(indices, "indices");
+    need_i32(coords, "coords", 3 * (int64_t)N); need_i32(indices, "indices", N);
     device_guard g(coords.device());
     ok(ngp_morton3D(ptr<int32_t>(coords), N, ptr<int32_t>(indices), stream_of(coords)), "morton3D");
 }
 
 void morton3D_invert(const at::Tensor indices, const uint32_t N, at::Tensor coords) {
-    on_gpu(indices, "indices"); on_gpu(coords, "coords");
+    need_i32(indices, "indices", N); need_i32(coords, "coords", 3 * (int64_t)N);
     device_guard g(indices.device());
     ok(ngp_morton3D_invert(ptr<int32_t>(indices), N, ptr<int32_t>(coords), stream_of(indices)), "morton3D_invert");
 }
 
 void packbits(const at::Tensor grid, const uint32_t N, const float density_thresh, at::Tensor bitfield) {
-    on_gpu(grid, "grid"); on_gpu(bitfield, "bitfield");
+    need_f32(grid, "grid", 8 * (int64_t)N); need_u8(bitfield, "bitfield", N);
     device_guard g(grid.device());
     ok(ngp_packbits(ptr<float>(grid), N, density_thresh, ptr<uint8_t>(bitfield), stream_of(grid)), "packbits");
 }
@@ -38,7 +40,10 @@ void march_rays_train(const at::Tensor rays_o, const at::Tensor rays_d, const at
                       const uint32_t max_steps, const uint32_t N, const uint32_t C, const uint32_t H, const uint32_t M, const at::Tensor nears,
                       const at::Tensor fars, at::Tensor xyzs, at::Tensor dirs, at::Tensor deltas, at::Tensor rays, at::Tensor counter,
                       const uint32_t perturb) {
-    on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(grid, "grid"); on_gpu(xyzs, "xyzs"); on_gpu(rays, "rays"); on_gpu(counter, "counter");
+    const int64_t n = N, m = M;
+    need_f32(rays_o, "rays_o", 3 * n); need_f32(rays_d, "rays_d", 3 * n); need_u8(grid, "grid", (int64_t)C * H * H * H / 8);
+    need_f32(nears, "nears", n); need_f32(fars, "fars", n); need_f32(xyzs, "xyzs", 3 * m); need_f32(dirs, "dirs", 3 * m); need_f32(deltas, "deltas", 2 * m);
+    need_i32(rays, "rays", 3 * n); need_i32(counter, "counter", 2);
     device_guard g(rays_o.device());
     at::Tensor ws = bytes_like(rays_o, ngp_march_rays_train_workspace_full(N, max_steps));       // the only hidden allocation, as the wrapper's
     ok(ngp_march_rays_train(ptr<float>(rays_o), ptr<float>(rays_d), ptr<uint8_t>(grid), bound, dt_gamma, max_steps, N, C, H, M, ptr<float>(nears),
@@ -48,7 +53,9 @@ void march_rays_train(const at::Tensor rays_o, const at::Tensor rays_d, const at
 
 void composite_rays_train_forward(const at::Tensor sigmas, const at::Tensor rgbs, const at::Tensor deltas, const at::Tensor rays, const uint32_t M,
                                   const uint32_t N, at::Tensor weights_sum, at::Tensor depth, at::Tensor image) {
-    on_gpu(sigmas, "sigmas"); on_gpu(rgbs, "rgbs"); on_gpu(deltas, "deltas"); on_gpu(rays, "rays");
+    const int64_t n = N, m = M;
+    need_f32(sigmas, "sigmas", m); need_f32(rgbs, "rgbs", 3 * m); need_f32(deltas, "deltas", 2 * m); need_i32(rays, "rays", 3 * n);
+    need_f32(weights_sum, "weights_sum", n); need_f32(depth, "depth", n); need_f32(image, "image", 3 * n);
     device_guard g(sigmas.device());
     ok(ngp_composite_rays_train_forward(ptr<float>(sigmas), ptr<float>(rgbs), ptr<float>(deltas), ptr<int32_t>(rays), M, N, ptr<float>(weights_sum),
                                         ptr<float>(depth), ptr<float>(image), stream_of(sigmas)), "composite_rays_train_forward");
@@ -57,7 +64,10 @@ void composite_rays_train_forward(const at::Tensor sigmas, const at::Tensor rgbs
 void composite_rays_train_backward(const at::Tensor grad_weights_sum, const at::Tensor grad_image, const at::Tensor sigmas, const at::Tensor rgbs,
                                    const at::Tensor deltas, const at::Tensor rays, const at::Tensor weights_sum, const at::Tensor image,
                                    const uint32_t M, const uint32_t N, at::Tensor grad_sigmas, at::Tensor grad_rgbs) {
-    on_gpu(grad_weights_sum, "grad_weights_sum"); on_gpu(grad_image, "grad_image"); on_gpu(sigmas, "sigmas"); on_gpu(rgbs, "rgbs");
+    const int64_t n = N, m = M;
+    need_f32(grad_weights_sum, "grad_weights_sum", n); need_f32(grad_image, "grad_image", 3 * n); need_f32(sigmas, "sigmas", m); need_f32(rgbs, "rgbs", 3 * m);
+    need_f32(deltas, "deltas", 2 * m); need_i32(rays, "rays", 3 * n); need_f32(weights_sum, "weights_sum", n); need_f32(image, "image", 3 * n);
+    need_f32(grad_sigmas, "grad_sigmas", m); need_f32(grad_rgbs, "grad_rgbs", 3 * m);
     device_guard g(sigmas.device());
     ok(ngp_composite_rays_train_backward(ptr<float>(grad_weights_sum), ptr<float>(grad_image), ptr<float>(sigmas), ptr<float>(rgbs), ptr<float>(deltas),
                                          ptr<int32_t>(rays), ptr<float>(weights_sum), ptr<float>(image), M, N, ptr<float>(grad_sigmas),
@@ -68,7 +78,12 @@ void march_rays(const uint32_t n_alive, const uint32_t n_step, const at::Tensor 
                 const at::Tensor rays_d, const float bound, const float dt_gamma, const uint32_t max_steps, const uint32_t C, const uint32_t H,
                 const at::Tensor grid, const at::Tensor nears, const at::Tensor fars, at::Tensor xyzs, at::Tensor dirs, at::Tensor deltas,
                 const uint32_t perturb) {
-    on_gpu(rays_alive, "rays_alive"); on_gpu(rays_t, "rays_t"); on_gpu(rays_o, "rays_o"); on_gpu(rays_d, "rays_d"); on_gpu(grid, "grid");
+    const int64_t m = (int64_t)n_alive * n_step;
+    need_i32(rays_alive, "rays_alive", n_alive); need_f32(rays_t, "rays_t", 0); need_f32(rays_o, "rays_o", 0); need_f32(rays_d, "rays_d", 0);
+    TORCH_CHECK(rays_o.numel() == rays_d.numel() && rays_o.numel() == 3 * rays_t.numel(), "march_rays: rays_o, rays_d must be [N,3] and rays_t [N]");
+    need_u8(grid, "grid", (int64_t)C * H * H * H / 8); need_f32(nears, "nears", rays_t.numel()); need_f32(fars, "fars", rays_t.numel());
+    TORCH_CHECK(xyzs.dim() == 2 && xyzs.size(0) >= m, "march_rays: xyzs must be [M,3] with M >= n_alive * n_step");
+    need_f32(xyzs, "xyzs", 3 * m); need_f32(dirs, "dirs", 3 * xyzs.size(0)); need_f32(deltas, "deltas", 2 * xyzs.size(0));
     device_guard g(rays_o.device());
     // the _fill form: the kernel writes every row (the reference wrapper's torch.zeros stays harmless) and answers "block empty" from a
     // coarse occupancy map it builds in this workspace
@@ -80,7 +95,10 @@ void march_rays(const uint32_t n_alive, const uint32_t n_step, const at::Tensor 
 
 void composite_rays(const uint32_t n_alive, const uint32_t n_step, at::Tensor rays_alive, at::Tensor rays_t, at::Tensor sigmas, at::Tensor rgbs,
                     at::Tensor deltas, at::Tensor weights_sum, at::Tensor depth, at::Tensor image) {
-    on_gpu(rays_alive, "rays_alive"); on_gpu(rays_t, "rays_t"); on_gpu(sigmas, "sigmas"); on_gpu(rgbs, "rgbs"); on_gpu(image, "image");
+    const int64_t m = (int64_t)n_alive * n_step;
+    need_i32(rays_alive, "rays_alive", n_alive); need_f32(rays_t, "rays_t", 0); need_f32(sigmas, "sigmas", m); need_f32(rgbs, "rgbs", 3 * m);
+    need_f32(deltas, "deltas", 2 * m); need_f32(weights_sum, "weights_sum", rays_t.numel()); need_f32(depth, "depth", rays_t.numel());
+    need_f32(image, "image", 3 * rays_t.numel());
     device_guard g(sigmas.device());
     ok(ngp_composite_rays(n_alive, n_step, ptr<int32_t>(rays_alive), ptr<float>(rays_t), ptr<float>(sigmas), ptr<float>(rgbs), ptr<float>(deltas),
                           ptr<float>(weights_sum), ptr<float>(depth), ptr<float>(image), stream_of(sigmas)), "composite_rays");

@@ -24,6 +24,18 @@ inline void on_gpu(const at::Tensor& t, const char* name) {
     TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
 }
 
+// dtype + size validation: the reference's raymarching entry points validate nothing and dispatch on the scalar type
+// (AT_DISPATCH_FLOATING_TYPES_AND_HALF, raymarching.cu:152-158 ...); these kernels are float32 / int32 / uint8 only, so anything else must be an
+// error here rather than reinterpreted memory
+inline void need(const at::Tensor& t, const char* name, at::ScalarType st, int64_t min_numel) {
+    on_gpu(t, name);
+    TORCH_CHECK(t.scalar_type() == st, name, " must be ", st, " (got ", t.scalar_type(), "); cast it, as the Python wrappers' custom_fwd(cast_inputs=float32) does");
+    TORCH_CHECK(t.numel() >= min_numel, name, " has ", t.numel(), " elements, this call reads or writes ", min_numel);
+}
+inline void need_f32(const at::Tensor& t, const char* name, int64_t n) { need(t, name, at::kFloat, n); }
+inline void need_i32(const at::Tensor& t, const char* name, int64_t n) { need(t, name, at::kInt, n); }
+inline void need_u8(const at::Tensor& t, const char* name, int64_t n) { need(t, name, at::kByte, n); }
+
 template <typename T> inline T* ptr(const at::Tensor& t) { return t.defined() && t.numel() ? (T*)t.data_ptr() : (T*)nullptr; }
 
 inline at::Tensor bytes_like(const at::Tensor& t, size_t n) {

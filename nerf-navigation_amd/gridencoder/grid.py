@@ -28,25 +28,27 @@ ROWS_FORWARD = True
 
 
 # The reference converts the float32 table to half on EVERY autocast forward (grid.py:38-39: 50 MB read + 25 MB written per call, 64
-# times per rendered frame).  The half copy is kept while the parameter is the same object with the same version counter, i.e. until an
-# optimiser step, load_state_dict or any in-place write changes it; training pays the conversion once per step as before.
-_HALF_TABLE = {"ref": None, "version": -1, "ptr": 0, "half": None}
+# times per rendered frame).  The half copy is kept ON THE PARAMETER (`embeddings._ngp_half`) while the parameter has the same version
+# counter and storage, and it is dropped
+#   * by every forward that will be differentiated with respect to the table (grad mode on and requires_grad: an optimiser step follows), and
+#   * by a post-accumulate-grad hook GridEncoder registers on its table: whenever a backward -- through this op, through the field's native
+#     training launches (ngp/field.py: _field_train, which never enters this function) or through anything else -- writes `.grad`, the copy
+#     goes, because not every optimiser announces its in-place update through `_version` (torch's fused Adam does not).
+def drop_half_table(embeddings):
+    embeddings._ngp_half = None
 
 
 def _half_table(embeddings, training):
-    """The float32 table rounded to half, kept between forwards of a frozen model (the drop-in inference loop encodes 64 times per frame:
-    2.1 ms of conversions).  A forward that will be differentiated with respect to the table never uses the copy and drops it: an
-    optimiser step follows, and not every optimiser announces its in-place update through `_version` (torch's fused Adam does not)."""
-    import weakref
-    c = _HALF_TABLE
+    """The float32 table rounded to half, kept between forwards of a model that is not being trained (the drop-in inference loop encodes 64
+    times per frame: 2.1 ms of conversions; `model.eval()` + `torch.no_grad()` is enough, the parameter need not be frozen)."""
     if training:
-        c.update(ref=None, version=-1, ptr=0, half=None)
+        embeddings._ngp_half = None
         return embeddings.detach().to(torch.half)
-    if (c["ref"] is not None and c["ref"]() is embeddings and c["version"] == embeddings._version and c["ptr"] == embeddings.data_ptr()
-            and c["half"].device == embeddings.device):
-        return c["half"]
+    c = getattr(embeddings, "_ngp_half", None)
+    if c is not None and c[0] == embeddings._version and c[1] == embeddings.data_ptr() and c[2].device == embeddings.device:
+        return c[2]
     half = embeddings.detach().to(torch.half)
-    c.update(ref=weakref.ref(embeddings), version=embeddings._version, ptr=embeddings.data_ptr(), half=half)
+    embeddings._ngp_half = (embeddings._version, embeddings.data_ptr(), half)
     return half
 
 
@@ -66,7 +68,9 @@ class _grid_encode(Function):
         H = base_resolution
 
         if torch.is_autocast_enabled() and C % 2 == 0:
-            embeddings = _half_table(embeddings, ctx.needs_input_grad[1]) if embeddings.dtype == torch.float32 else embeddings.to(torch.half)
+            # "training" = this forward is differentiated w.r.t. the table; ctx.needs_input_grad[1] is True under no_grad as well
+            training = torch.is_grad_enabled() and embeddings.requires_grad
+            embeddings = _half_table(embeddings, training) if embeddings.dtype == torch.float32 else embeddings.to(torch.half)
         embeddings = embeddings.contiguous()
         if inputs.dtype != torch.float32:
             raise RuntimeError("inputs must be a float32 tensor")
@@ -174,6 +178,8 @@ class GridEncoder(nn.Module):
 
         self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
         self.reset_parameters()
+        # any backward that writes embeddings.grad is followed by an optimiser step: cached half copies of the table die here (see _half_table)
+        self.embeddings.register_post_accumulate_grad_hook(drop_half_table)
 
     def reset_parameters(self):
         std = 1e-4

@@ -114,8 +114,14 @@ class _field_train(Function):
 class _ParamEpoch:
     """Cached derived copies of the parameters (half table, packed weights, the nav kernels' transposes) are keyed on the tensors'
     `_version` counters AND on this epoch.  Not every in-place update bumps `_version` (torch's fused Adam updates parameters without
-    it), but every optimiser step follows a forward that is differentiated with respect to the parameters -- and that forward advances
-    the epoch, so a later frozen-model call rebuilds its copies.  `mark_updated()` is for callers that write parameters by other means."""
+    it), so the epoch advances
+      * whenever a backward writes the `.grad` of one of the field's parameters (post-accumulate-grad hooks, `_watch_parameters`): an
+        optimiser step can only come after that, and it comes AFTER the training forward -- which itself fills the cache with the
+        pre-step copies (`_field_train.forward` calls `fused_state`), so advancing at the forward alone would leave those copies valid
+        for the first frozen-model call after the step (ADVICE r2);
+      * at every forward that is differentiated with respect to the parameters (kept: it costs nothing and covers a caller that swaps
+        parameter storage between steps).
+    `mark_updated()` is for callers that write parameters by other means (load_state_dict does bump `_version`; `p.data = ...` does not)."""
     _param_epoch = 0
 
     def _training_forward(self):
@@ -124,6 +130,18 @@ class _ParamEpoch:
 
     def mark_updated(self):
         self._param_epoch += 1
+
+    def _watch_parameters(self):
+        """call at the end of __init__: every parameter's gradient accumulation advances the epoch (the hook holds the module weakly)"""
+        import weakref
+        ref = weakref.ref(self)
+
+        def bump(_param):
+            me = ref()
+            if me is not None:
+                me._param_epoch += 1
+        for p in self.parameters():
+            p.register_post_accumulate_grad_hook(bump)
 
 
 class NGPFieldFF(_ParamEpoch, nn.Module):
@@ -143,6 +161,7 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         self._fused = None
         self.fused_training = True           # training forwards under autocast go through _field_train when the field has the default shape
         self.fused_inference = True          # forwards without gradients under autocast go through forward_fused (one launch), likewise
+        self._watch_parameters()
 
     def _fused_training_applies(self, x, d):
         p = self.encoder.embeddings
@@ -296,6 +315,7 @@ class NGPField(_ParamEpoch, nn.Module):
             self.encoder_bg, self.in_dim_bg = get_encoder("hashgrid", input_dim=2, num_levels=4, log2_hashmap_size=19, desired_resolution=2048)
             dims = [self.in_dim_bg + self.in_dim_dir] + [hidden_dim_bg] * (num_layers_bg - 1) + [3]
             self.bg_net = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers_bg)])
+        self._watch_parameters()
 
     @staticmethod
     def _mlp(layers, h):

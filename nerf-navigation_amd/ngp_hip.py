@@ -7,6 +7,7 @@ test can never pass on a silent CPU/eager path.
 import ctypes
 import os
 import subprocess
+import threading
 
 import torch
 
@@ -110,6 +111,51 @@ def build(verbose=False):
 
 
 _lib = None
+_ACTIVE = threading.local()
+
+
+class _GuardedCall:
+    """One entry point of the library behind a DEVICE GUARD (SURVEY 8b "Threading / streams": the reference launches on the legacy default
+    stream of whatever device is current; the pybind shims guard with c10's OptionalHIPGuard, this is the ctypes side of the same rule).
+    The device is that of the first tensor argument (`ptr(t)` objects carry their tensor).  When it is not the current device the call runs
+    inside `torch.cuda.device(that device)`, and the `stream()` argument -- resolved only when ctypes converts it, i.e. inside the guard --
+    is torch's current stream OF THAT DEVICE.  Tensors on two different devices in one call raise instead of launching."""
+    __slots__ = ("fn", "name")
+
+    def __init__(self, fn, name):
+        self.fn, self.name = fn, name
+
+    def __call__(self, *args):
+        dev = None
+        for a in args:
+            if type(a) is _DevPtr:
+                d = a.tensor.device
+                if dev is None:
+                    dev = d
+                elif d != dev:
+                    raise RuntimeError(f"libngp_hip {self.name}: tensors on {dev} and {d} in one call")
+        if dev is None or dev.type != "cuda":
+            return self.fn(*args)
+        _ACTIVE.device = dev                                 # `stream()` arguments resolve to this device's current stream
+        try:
+            if dev.index == torch.cuda.current_device():
+                return self.fn(*args)
+            with torch.cuda.device(dev):
+                return self.fn(*args)
+        finally:
+            _ACTIVE.device = None
+
+
+class _GuardedLib:
+    """attribute access returns the guarded entry points; `raw` is the ctypes handle"""
+
+    def __init__(self, handle):
+        self.raw = handle
+
+    def __getattr__(self, name):
+        call = _GuardedCall(getattr(self.raw, name), name)
+        self.__dict__[name] = call
+        return call
 
 
 def lib():
@@ -125,7 +171,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
+        _lib = _GuardedLib(handle)
     return _lib
 
 
@@ -184,9 +230,22 @@ def ptr(t):
     return _DevPtr(t)
 
 
+class _CurrentStream:
+    """The HIP stream torch is enqueueing on FOR THE CURRENT DEVICE AT THE MOMENT OF THE CALL: ctypes reads `_as_parameter_` while it converts
+    the arguments, which happens inside `_GuardedCall`'s device guard, so a call on a cuda:1 tensor made while cuda:0 is current gets cuda:1's
+    stream (the reference used the legacy default stream of the current device)."""
+    __slots__ = ()
+
+    @property
+    def _as_parameter_(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(getattr(_ACTIVE, "device", None)).cuda_stream)
+
+
+_STREAM = _CurrentStream()
+
+
 def stream():
-    """The HIP stream torch is currently enqueueing on (the reference used the legacy default stream)."""
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM
 
 
 def require_cuda(*tensors):

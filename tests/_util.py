@@ -85,3 +85,19 @@ def ff_model_matrices(model):
         assert off == flat.size
         return out
     return split(model["sigma_weights"], 2), split(model["color_weights"], 3)
+
+
+def linear_field_from_model(model, dev):
+    """ngp.field.NGPField (nn.Linear layers, float32) holding the numbers of a workload.make_model() dict: the FFMLP shapes 32-64-64-16 and
+    32-64-64-64-16 as Linear stacks (the colour net's zero input column and its 13 unused output rows dropped, nerf/network_ff.py:67-74)."""
+    import torch
+    from ngp.field import NGPField
+    sw, cw = ff_model_matrices(model)
+    field = NGPField(bound=model["bound"], num_layers=3, num_layers_color=4).to(dev)
+    cw = [cw[0][:, :31]] + cw[1:-1] + [cw[-1][:3]]
+    with torch.no_grad():
+        field.encoder.embeddings.copy_(torch.from_numpy(model["embeddings"]))
+        for layer, w in zip(list(field.sigma_net) + list(field.color_net), sw + cw):
+            assert tuple(layer.weight.shape) == w.shape, (layer.weight.shape, w.shape)
+            layer.weight.copy_(torch.from_numpy(np.ascontiguousarray(w)))
+    return field

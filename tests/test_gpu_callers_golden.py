@@ -1,0 +1,274 @@
+"""GPU: the HIP callers against the golden vectors that EXECUTED REFERENCE PYTHON produced (tests/golden/make_callers_golden.py: nerf/utils.py,
+nerf/renderer.py from /root/reference over the oracle's leaf ops; the same files pin the oracle in tests/test_callers_golden.py).
+Rows: R1 run_cuda inference loop (+ the fused frame), R2 training branch, R3 run + sample_pdf, R4 update_extra_state / mark_untrained_grid
+(native ops), R5 get_rays (native op).  The model is workload.make_model(0) (seeded numpy, rebuilt here), once as float32 nn.Linear layers
+(tight tolerances: float32 on both sides, different summation orders) and once as the FFMLP field under autocast (half tolerances)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+importlib.import_module("nerf-navigation_amd")
+pytestmark = pytest.mark.gpu
+
+from _util import ff_grads_as_matrices, linear_field_from_model  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def model():
+    from ngp import workload as W
+    return W.make_model(0)
+
+
+@pytest.fixture(scope="module")
+def linear_field(model, dev):
+    return linear_field_from_model(model, dev)
+
+
+@pytest.fixture(scope="module")
+def ff_field(model, dev):
+    from ngp.field import NGPFieldFF
+    return NGPFieldFF(bound=model["bound"]).to(dev).load_arrays(model)
+
+
+def ring_renderer(field, dev, **kw):
+    from ngp import workload as W
+    from ngp.render import NGPRenderer
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0, min_near=0.2, **kw).to(dev)
+    if kw.get("grid_size", 128) == 128:
+        ren.load_density_grid(W.density_grid())
+    return ren
+
+
+def test_get_rays_native_against_reference(dev):
+    """R5: ngp_get_rays (csrc/ngp_camera.h) == nerf/utils.py:53-116 executed, full image and the pixel subset the reference drew; the kernel
+    associates the norm and the 3x3 product in its own fixed order: <= 2 ulp of 1 on the directions, origins exact."""
+    from ngp.nav import get_rays, get_rays_native
+    g = gold("callers_tier1")
+    H, Wd = (int(v) for v in g["gr_HW"])
+    for b in range(2):
+        o, d = get_rays_native(g["gr_poses"][b], g["gr_intrinsics"], H, Wd, device=dev)
+        np.testing.assert_array_equal(o.cpu().numpy(), g["gr_full_o"][b])
+        assert np.max(np.abs(d.cpu().numpy() - g["gr_full_d"][b])) <= 2.5e-7
+        o, d = get_rays_native(g["gr_poses"][b], g["gr_intrinsics"], H, Wd, inds=t(g["gr_rand_inds"][b], dev))
+        assert np.max(np.abs(d.cpu().numpy() - g["gr_rand_d"][b])) <= 2.5e-7
+        np.testing.assert_array_equal(o.cpu().numpy(), g["gr_rand_o"][b])
+    res = get_rays(t(g["gr_poses"], dev), g["gr_intrinsics"], H, Wd)                     # the torch form on the GPU
+    assert np.max(np.abs(res["rays_d"].cpu().numpy() - g["gr_full_d"])) <= 2.5e-7
+
+
+def test_sample_pdf_on_gpu_against_reference(dev, monkeypatch):
+    """sample_pdf (nerf/renderer.py:12-46) on device tensors, det and random with the recorded uniforms.  The GPU's cumsum rounds in another order
+    (1 ulp of the CDF) and the inversion divides by CDF differences as small as 1e-5 (:42-43): 5e-5 of depth."""
+    from ngp import render
+    g = gold("callers_tier1")
+    bins, wts, n = t(g["pdf_bins"], dev), t(g["pdf_weights"], dev), g["pdf_det"].shape[1]
+    assert np.max(np.abs(render.sample_pdf(bins, wts, n, det=True).cpu().numpy() - g["pdf_det"])) < 5e-5
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: t(g["pdf_u"], dev))
+    assert np.max(np.abs(render.sample_pdf(bins, wts, n, det=False).cpu().numpy() - g["pdf_rand"])) < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["fixed", "upsample", "perturb"])
+def test_run_against_reference_run(linear_field, dev, tag, monkeypatch):
+    """R3 / N2: NGPRenderer.run on the GPU == NeRFRenderer.run (nerf/renderer.py:125-254) executed on the CPU: image / depth / weights_sum
+    2e-4 (float32 sums over 64-80 samples through a 16-level encoder in two orders); d loss / d rays 2e-3 in norm (5e-3 with resampling)."""
+    from ngp import workload as W
+    from ngp.render import NGPRenderer
+    g = gold("callers_run")
+    ns, us, pert = (int(v) for v in g[f"{tag}_kw"])
+    ren = NGPRenderer(linear_field, bound=W.BOUND, cuda_ray=False, min_near=0.2, density_thresh=10.0).to(dev).eval()
+    o, d = t(g["rays_o"], dev)[None].requires_grad_(True), t(g["rays_d"], dev)[None].requires_grad_(True)
+    if pert:
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: t(g[f"{tag}_u"], dev))
+    res = ren.run(o, d, bg_color=1.0, num_steps=ns, upsample_steps=us, perturb=bool(pert))
+    monkeypatch.undo()
+    hit = torch.isfinite(res["depth"][0])
+    loss = (res["image"][0] * t(g["w_image"], dev)).sum() + (res["depth"][0][hit] * t(g["w_depth"], dev)[hit]).sum()
+    loss.backward()
+    ref_depth = g[f"{tag}_depth"]
+    fin = np.isfinite(ref_depth)
+    assert np.array_equal(np.isfinite(res["depth"][0].detach().cpu().numpy()), fin)
+    assert np.max(np.abs(res["image"][0].detach().cpu().numpy() - g[f"{tag}_image"])) < 2e-4
+    assert np.max(np.abs(res["weights_sum"].detach().cpu().numpy() - g[f"{tag}_weights_sum"])) < 2e-4
+    assert np.max(np.abs(res["depth"][0].detach().cpu().numpy()[fin] - ref_depth[fin])) < 2e-4
+    gtol = 5e-3 if us else 2e-3
+    for mine, ref in ((o.grad[0].cpu().numpy(), g[f"{tag}_grad_o"]), (d.grad[0].cpu().numpy(), g[f"{tag}_grad_d"])):
+        ok = np.isfinite(ref).all(axis=1) & fin
+        assert rel(mine[ok], ref[ok]) < gtol
+        assert np.abs(ref[ok]).max() > 1e-3
+
+
+@pytest.mark.parametrize("tag, dt_gamma, bg", [("inf", 0.0, 1.0), ("inf2", 1 / 128, (0.2, 0.5, 0.7))])
+def test_run_cuda_inference_against_reference_loop(linear_field, ff_field, dev, tag, dt_gamma, bg):
+    """R1: run_cuda's inference branch on the GPU == the reference's loop (nerf/renderer.py:325-374) executed.  float32 field: the schedule
+    (n_alive, n_step) per iteration equal except where a ray's `T < 1e-4` decision sits inside float32 rounding (<= 2 rays per iteration),
+    image 1e-4, depth 1e-4.  FFMLP field under autocast, per op and fused into one launch: image 5e-3 (half activations)."""
+    g = gold("callers_run_cuda")
+    ro, rd = t(g[f"{tag}_rays_o"], dev)[None], t(g[f"{tag}_rays_d"], dev)[None]
+    bgc = bg if np.isscalar(bg) else t(np.asarray(bg, np.float32), dev)
+    ref_img, ref_depth, ref_trace = g[f"{tag}_image"], g[f"{tag}_depth"], g[f"{tag}_trace"]
+    fin = np.isfinite(ref_depth)
+    ren = ring_renderer(linear_field, dev).eval()
+    trace = []
+    with torch.no_grad():
+        out = ren.run_cuda(ro, rd, dt_gamma=dt_gamma, bg_color=bgc, perturb=False, max_steps=1024, trace=trace)
+    trace = np.array(trace, np.int64)
+    assert abs(len(trace) - len(ref_trace)) <= 2
+    k = min(len(trace), len(ref_trace)) - 2
+    assert np.array_equal(trace[:k, 1], ref_trace[:k, 1]) and np.max(np.abs(trace[:k, 0] - ref_trace[:k, 0])) <= 2
+    assert np.max(np.abs(out["image"][0].cpu().numpy() - ref_img)) < 1e-4
+    depth = out["depth"][0].cpu().numpy()
+    assert np.array_equal(np.isfinite(depth), fin) and np.max(np.abs(depth[fin] - ref_depth[fin])) < 1e-4
+
+    ren_ff = ring_renderer(ff_field, dev).eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        per_op = ren_ff.run_cuda(ro, rd, dt_gamma=dt_gamma, bg_color=bgc, perturb=False, max_steps=1024, fused_field=False)
+        one = ren_ff.run_cuda(ro, rd, dt_gamma=dt_gamma, bg_color=bgc, perturb=False, max_steps=1024)
+    assert np.max(np.abs(per_op["image"][0].float().cpu().numpy() - ref_img)) < 5e-3
+    assert np.max(np.abs(one["image"][0].float().cpu().numpy() - ref_img)) < 5e-3
+    fused = ren_ff.render_fused(ro, rd, dt_gamma=dt_gamma, bg_color=bg, max_steps=1024)
+    assert np.max(np.abs(fused["image"][0].cpu().numpy() - ref_img)) < 5e-3
+    fd = fused["depth"][0].cpu().numpy()
+    assert np.max(np.abs(fd[fin] - ref_depth[fin])) < 5e-3
+    # samples evaluated: the loop evaluates whole n_step chunks (a ray that turns opaque inside a chunk still has the rest of it evaluated), the
+    # fused kernel stops a ray at the end of its slab: the totals agree to a few percent, not exactly
+    assert abs(int(fused["stats"][0]) - int(ref_trace[:, 2].sum())) <= 0.03 * ref_trace[:, 2].sum()
+
+
+def _check_table_digest(g, tag, grad, tol):
+    grad = np.asarray(grad, np.float64)
+    assert np.linalg.norm(grad) == pytest.approx(float(g[f"{tag}_grad_table_norm"]), rel=tol)
+    ref = g[f"{tag}_grad_table_values"].astype(np.float64)
+    assert rel(grad[g[f"{tag}_grad_table_rows"]], ref) < tol
+    return np.flatnonzero(np.any(grad != 0, axis=1)).size
+
+
+@pytest.mark.parametrize("tag, perturb", [("trn", False), ("trnp", True)])
+def test_run_cuda_training_against_reference(linear_field, dev, tag, perturb):
+    """R2: the training branch on the GPU (float32 nn.Linear field) == the reference's (nerf/renderer.py:282-323) executed: counter bit-exact,
+    image / depth / weights_sum 1e-5, weight gradients 1e-4 in norm, table gradient (4,096 recorded rows + norm + rows touched) 1e-4."""
+    g = gold("callers_run_cuda")
+    ren = ring_renderer(linear_field, dev).train()
+    for p in linear_field.parameters():
+        p.grad = None
+    out = ren.run_cuda(t(g["trn_rays_o"], dev)[None], t(g["trn_rays_d"], dev)[None], dt_gamma=0, bg_color=1.0, perturb=perturb,
+                       force_all_rays=False, max_steps=1024)
+    slot = 0 if tag == "trn" else 1
+    np.testing.assert_array_equal(ren.step_counter[0].cpu().numpy(), g[f"{tag}_counter"][slot])
+    assert np.max(np.abs(out["image"][0].detach().cpu().numpy() - g[f"{tag}_image"])) < 1e-5
+    assert np.max(np.abs(out["depth"][0].detach().cpu().numpy() - g[f"{tag}_depth"])) < 1e-5
+    assert np.max(np.abs(out["weights_sum"].detach().cpu().numpy() - g[f"{tag}_weights_sum"])) < 1e-5
+    (out["image"][0] * t(g["trn_w_image"], dev)).sum().backward()
+    layers = list(linear_field.sigma_net) + list(linear_field.color_net)
+    refs = [g[f"{tag}_grad_sigma_w{k}"] for k in range(3)] + [g[f"{tag}_grad_color_w{k}"] for k in range(4)]
+    refs[3], refs[6] = refs[3][:, :31], refs[6][:3]
+    for layer, ref in zip(layers, refs):
+        assert rel(layer.weight.grad.cpu().numpy(), ref) < 1e-4
+    rows = _check_table_digest(g, tag, linear_field.encoder.embeddings.grad.cpu().numpy(), 1e-4)
+    assert rows == int(g[f"{tag}_grad_table_n_rows"])
+
+
+def test_run_cuda_training_ffmlp_autocast_against_reference(ff_field, dev):
+    """R2 + M2 as main_nerf.py runs it (--ff --fp16): native field launches under autocast against the float32 reference run: image 4e-3,
+    weight gradients 3e-2 in norm, table gradient 5e-2 (half activations, half atomics); counter bit-exact; mean_count feedback."""
+    g = gold("callers_run_cuda")
+    ren = ring_renderer(ff_field, dev).train()
+    for p in ff_field.parameters():
+        p.grad = None
+    scale = 128.0
+    ro, rd = t(g["trn_rays_o"], dev)[None], t(g["trn_rays_d"], dev)[None]
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = ren.run_cuda(ro, rd, dt_gamma=0, bg_color=1.0, perturb=False, force_all_rays=False, max_steps=1024)
+        loss = (out["image"][0] * t(g["trn_w_image"], dev)).sum()
+    (loss * scale).backward()
+    np.testing.assert_array_equal(ren.step_counter[0].cpu().numpy(), g["trn_counter"][0])
+    assert np.max(np.abs(out["image"][0].detach().float().cpu().numpy() - g["trn_image"])) < 4e-3
+    gs = [m / scale for m in ff_grads_as_matrices(ff_field.sigma_net)] + [m / scale for m in ff_grads_as_matrices(ff_field.color_net)]
+    refs = [g[f"trn_grad_sigma_w{k}"] for k in range(3)] + [g[f"trn_grad_color_w{k}"] for k in range(4)]
+    for mine, ref in zip(gs, refs):
+        assert rel(mine, ref) < 3e-2
+    _check_table_digest(g, "trn", ff_field.encoder.embeddings.grad.float().cpu().numpy() / scale, 5e-2)
+    # second call with perturb, then the counter ring -> mean_count -> bounded third march (raymarching.py:196-203)
+    with torch.autocast("cuda", dtype=torch.float16):
+        ren.run_cuda(ro, rd, dt_gamma=0, bg_color=1.0, perturb=True, max_steps=1024)
+    np.testing.assert_array_equal(ren.step_counter[:2].cpu().numpy(), g["trnp_counter"][:2])
+    total = min(16, ren.local_step)
+    ren.mean_count = int(ren.step_counter[:total, 0].sum().item() / total)
+    assert ren.mean_count == int(g["trn3_mean_count"])
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        out3 = ren.run_cuda(ro, rd, dt_gamma=0, bg_color=1.0, perturb=False, max_steps=1024)
+    np.testing.assert_array_equal(ren.step_counter[2].cpu().numpy(), g["trn3_counter"][2])
+    assert np.max(np.abs(out3["image"][0].float().cpu().numpy() - g["trn3_image"])) < 4e-3
+
+
+def test_density_grid_refresh_against_reference(linear_field, dev):
+    """R4: NGPRenderer.update_extra_state (native ops, csrc/density_grid.hip) == the reference's update_extra_state (nerf/renderer.py:446-537)
+    executed with the pcg32 numbers the native op draws.  float32 densities from two devices: grid 1e-4 relative (+1e-6) on every cell written
+    once; cells written by several samples: native >= reference (largest vs an arbitrary writer); bitfield equal outside the threshold gap;
+    mean_count exact."""
+    from ngp import workload as W
+    from oracle import callers_oracle as CO
+    from oracle import ngp_oracle as O
+    g = gold("callers_grid")
+    H, seed, cas = int(g["H"]), int(g["seed"]), 2
+    ren = ring_renderer(linear_field, dev, grid_size=H)
+    ren.grid_seed = seed
+    ren.step_counter[0, 0], ren.step_counter[1, 0], ren.local_step = 1000, 1301, 2
+    ren.update_extra_state(decay=0.95, S=H)
+    grid = ren.density_grid.cpu().numpy()
+    ref = g["full_grid"]
+    assert np.max(np.abs(grid - ref) / (np.abs(ref) + 1e-2)) < 1e-4
+    assert ren.mean_density == pytest.approx(float(g["full_mean_density"]), rel=1e-4)
+    assert ren.mean_count == int(g["full_mean_count"])
+
+    def bits_ok(bitfield, bitfield_ref, ref_grid, thresh, thresh_ref, exclude, share):
+        lo, hi = min(thresh, thresh_ref) * (1 - 2e-4), max(thresh, thresh_ref) * (1 + 2e-4)
+        decided = ~exclude & ~((ref_grid >= lo) & (ref_grid <= hi))
+        a = np.unpackbits(bitfield, bitorder="little").astype(bool).reshape(ref_grid.shape)
+        b = np.unpackbits(bitfield_ref, bitorder="little").astype(bool).reshape(ref_grid.shape)
+        assert np.array_equal(a[decided], b[decided]) and decided.mean() > share
+    bits_ok(ren.density_bitfield.cpu().numpy(), g["full_bitfield"], ref, min(ren.mean_density, 10.0), min(float(g["full_mean_density"]), 10.0),
+            np.zeros_like(ref, bool), 0.99)
+
+    # partial sweep from the REFERENCE's grid (so that both pick among the same occupied cells)
+    ren.density_grid.copy_(t(ref, dev))
+    ren.iter_density = 16
+    ren.update_extra_state(decay=0.95, S=H)
+    n_occ = [(ref[c] > 0).sum() for c in range(cas)]
+    rnd = CO.grid_update_randoms(seed, 16, cas, H, partial=True, n_occ=n_occ)
+    dup = np.zeros((cas, H ** 3), bool)
+    for c in range(cas):
+        idx = np.concatenate([O.morton3D(np.asarray(rnd["coords"][c], np.int32)).astype(np.int64), np.flatnonzero(ref[c] > 0)[rnd["pick"][c]]])
+        u, n = np.unique(idx, return_counts=True)
+        dup[c, u[n > 1]] = True
+    grid2, ref2 = ren.density_grid.cpu().numpy(), g["partial_grid"]
+    assert np.max(np.abs(grid2 - ref2)[~dup] / (np.abs(ref2[~dup]) + 1e-2)) < 1e-4
+    assert np.all(grid2[dup] >= ref2[dup] * (1 - 1e-4) - 1e-6)
+    bits_ok(ren.density_bitfield.cpu().numpy(), g["partial_bitfield"], ref2, min(ren.mean_density, 10.0), min(float(g["partial_mean_density"]), 10.0), dup, 0.5)
+
+
+def test_mark_untrained_grid_against_reference(linear_field, dev):
+    """R4: ngp_mark_untrained_grid == mark_untrained_grid (nerf/renderer.py:381-442) executed, cell for cell"""
+    g = gold("callers_grid")
+    H, cas = int(g["H"]), 2
+    ren = ring_renderer(linear_field, dev, grid_size=H)
+    ren.mark_untrained_grid(g["mark_poses"], g["mark_intrinsics"])
+    unseen = np.unpackbits(g["mark_unseen"]).astype(bool)[:cas * H ** 3].reshape(cas, -1)
+    np.testing.assert_array_equal(ren.density_grid.cpu().numpy() < 0, unseen)
