@@ -35,6 +35,8 @@ LANE_ADDRESSES_PER_SAMPLE = 11 * 8 + 5 * 4   # per-lane gather addresses the tex
 LINES_PER_SAMPLE = 5 * 4 + 11 * 4.25
 
 
+MODEL_NAMES = {"handset": "hand-set (table and weights set by hand to represent the scene; bit-reproducible)",
+               "trained": "fitted (a fresh field trained on renders of the hand-set scene with the package's trainer, seed 0)"}
 ATOMIC_PEAK_GBS = 1300.0               # MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of added bytes, chip-wide
 SCATTER_BYTES_PER_POINT = 512          # 16 levels x 8 corners x 2 features x 2 B of half2 atomics (SURVEY 8d "training extra")
 
@@ -108,8 +110,7 @@ def bench_train(args, rank, world, dev, W, teacher):
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sharding.barrier()
         torch.cuda.synchronize()
 
     def points_now():
@@ -169,7 +170,7 @@ def bench_train(args, rank, world, dev, W, teacher):
             "roofline": roof(points, scatter_ms),
             "warmup_phase": {"ms_per_step": 1e3 * warm[0] / args.steps, "points_per_step": warm[2], "loss": warm[1],
                              "roofline": roof(warm[2], warm[3], profiled_phase=True)}}))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -206,6 +207,64 @@ def fit_model(args, dev, W, teacher):
                      "occupied_cells": int(torch.count_nonzero(student.density_grid > min(student.mean_density, 10.0)))}
 
 
+def psnr_ref(pred, truth):
+    """PSNRMeter.update's formula (nerf/utils.py:203-210): -10 log10(mean((pred - truth)^2)), peak value 1"""
+    return float(-10 * np.log10(np.mean((np.asarray(pred, np.float32) - np.asarray(truth, np.float32)) ** 2)))
+
+
+def fitted_block(args, dev, W, teacher, rays, Wd):
+    """SURVEY 8d cfg 2 as contracted: the SAME frame kernel on a model fitted for --fit-steps steps (seed 0) with the package's own trainer --
+    untimed fit, then --fit-frames timed 800x800 launches with HIP events -- plus the north_star's PSNR criterion on a <= 200^2 view:
+    psnr_delta_db = PSNR(HIP render of the student, teacher) - PSNR(CPU-oracle render of the same student, teacher)."""
+    from oracle import ngp_oracle as O, render_oracle as R
+    student, fit = fit_model(args, dev, W, teacher)
+    N = rays[0][0].shape[1]
+    for k in range(5):
+        student.render_fused(*rays[k % len(rays)], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
+    torch.cuda.synchronize()
+    ev, stats = [], []
+    t0 = time.perf_counter()
+    for k in range(args.fit_frames):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = student.render_fused(*rays[k % len(rays)], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
+        b.record()
+        ev.append((a, b)); stats.append(out["stats"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    samples = int(torch.stack(stats)[:, 0].to(torch.int64).sum().item())
+    kernel_s = 1e-3 * float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    per_launch = samples / args.fit_frames
+    achieved = GATHER_BYTES_PER_SAMPLE * per_launch / kernel_s / 1e9
+    block = {"model": MODEL_NAMES["trained"], "fit": fit, "frames": args.fit_frames, "value": samples / elapsed, "unit": "ray-samples/s",
+             "ms_per_step": 1e3 * elapsed / args.fit_frames, "fps": args.fit_frames / elapsed, "samples_per_ray": per_launch / N,
+             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                          "kernel": "k_render_frame_multi", "avg_launch_ms": 1e3 * kernel_s}}
+    if not args.no_cpu:
+        O.build()
+        cpu_threads = int(os.environ.get("NGP_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+        O.set_threads(cpu_threads)
+        f = student.field
+        sm = dict(embeddings=f.encoder.embeddings.detach().float().cpu().numpy(), offsets=f.encoder.offsets.cpu().numpy(),
+                  per_level_scale=float(f.encoder.per_level_scale), sigma_weights=f.sigma_net.weights.detach().float().cpu().numpy(),
+                  color_weights=f.color_net.weights.detach().float().cpu().numpy(), bound=W.BOUND)
+        r = min(int(args.fit_cpu_res), 200)
+        radius, height = W.scene_orbit(args.workload)
+        o, d = W.get_rays(W.orbit_pose(3, 8, radius, height), W.intrinsics(r, r), r, r)       # a view between two training views
+        to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+        truth = teacher.render_fused(to, td, bg_color=1, image_width=r)["image"][0].cpu().numpy()
+        hip = student.render_fused(to, td, bg_color=1, image_width=r)["image"][0].cpu().numpy()
+        t1 = time.perf_counter()
+        ref = R.run_cuda(lambda x, dd: R.field_forward(sm, x, dd, 1.0), o, d, student.density_bitfield.cpu().numpy(), W.BOUND, 2)
+        cpu_s = time.perf_counter() - t1
+        p_hip, p_cpu = psnr_ref(hip, truth), psnr_ref(ref["image"], truth)
+        block.update({"psnr_view": f"{r}x{r}, orbit pose 3 of 8 (not a training view)", "psnr_hip_vs_teacher_db": p_hip, "psnr_oracle_vs_teacher_db": p_cpu,
+                      "psnr_delta_db": p_hip - p_cpu, "psnr_vs_oracle_db": psnr_ref(hip, ref["image"]),
+                      "max_abs_vs_oracle": float(np.max(np.abs(hip - ref["image"]))), "oracle_seconds": cpu_s, "oracle_ray_samples": ref["samples"],
+                      "criterion": "north_star: PSNR within 0.1 dB of the CPU path", "criterion_met": bool(abs(p_hip - p_cpu) < 0.1)})
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +277,10 @@ def main():
                          "renders of it with the package's own trainer for --fit-steps steps, seed 0 (SURVEY 8d), then rendered")
     ap.add_argument("--fit-steps", type=int, default=2000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-fit", action="store_true", help="skip the `fitted` block (the same frame kernel timed on a model fitted for --fit-steps steps, SURVEY 8d cfg 2)")
+    ap.add_argument("--fit-frames", type=int, default=30, help="timed 800x800 frames of the fitted model (after 5 warm-up frames)")
+    ap.add_argument("--fit-cpu-res", type=int, default=200, help="side of the view on which the fitted student is rendered by the CPU oracle too (psnr_delta_db); <= 200")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: initialise the nccl (= RCCL) process group anyway and take every collective of the N > 1 path")
     ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "drop_in", "per_op", "per_op_fused_field"],
                     help="fused = headline (rays resident); fused_camera = rays generated inside the frame kernel from the pose; "
                          "fused_torch_rays = torch get_rays per frame + fused; drop_in = run_cuda as an unmodified renderer runs it (the field picks its one-launch route); "
@@ -243,12 +306,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or args.force_dist:
+        if world == 1:                                       # --force-dist: a single-rank RCCL group (no launcher: rendezvous on the loopback)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+    use_dist = dist.is_initialized()
 
     importlib.import_module("nerf-navigation_amd")
     from ngp import workload as W
@@ -262,6 +331,8 @@ def main():
     ren.load_density_grid(grid)
 
     if args.mode == "train":
+        from ngp import sharding as _sh
+        _sh.FORCE_COLLECTIVES = bool(args.force_dist)
         return bench_train(args, rank, world, dev, W, ren)
 
     fit = None
@@ -274,6 +345,7 @@ def main():
     n_poses = 8
     radius, height = W.scene_orbit(args.workload)
     from ngp import sharding
+    sharding.FORCE_COLLECTIVES = bool(args.force_dist)
     strong = args.scaling == "strong" and world > 1
     rays, poses = [], []
     if strong:
@@ -315,8 +387,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sharding.barrier()                                   # a no-op without a process group (N = 1 and no --force-dist)
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
@@ -348,7 +419,7 @@ def main():
     samples_all, elapsed_max = sharding.reduce_throughput(samples, elapsed, dev)   # sum of samples, max of wall time
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -372,7 +443,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"S-{args.workload} {H}x{Wd} novel-view render (synthetic Stonehenge stand-in, bound 2, dt_gamma 0, max_steps 1024), "
+                        f"model={MODEL_NAMES[args.model]}, "
                         f"hashgrid(16x2, 2^19, f16) + FFMLP(32-64-64-16 | 32-64-64-64-16) + occupancy march, path={args.path}",
+            "model": args.model,
+            "collectives": "nccl (RCCL), forced on a single rank" if (args.force_dist and world == 1) else ("nccl (RCCL)" if use_dist and not rehearsal else ("gloo rehearsal" if use_dist else "none (one process)")),
             "rays_per_frame": N,
             "row_band_per_gpu": f"{hi - lo} of {H} rows" if strong else "all rows",
             "frames_per_gpu": args.steps,
@@ -427,8 +501,9 @@ def main():
             result["roofline"]["traffic_stale"] = info
 
     if fit is not None:
-        result["config"]["model"] = "trained"
         result["fit"] = fit
+    if args.model == "handset" and args.path == "fused" and world == 1 and not strong and not args.no_fit:
+        result["fitted"] = fitted_block(args, dev, W, ren, rays, Wd)
     if not args.no_cpu and world == 1:
         from oracle import ngp_oracle as O, render_oracle as R
         O.build()
@@ -471,7 +546,7 @@ def main():
                       f"{ref['samples']} ray-samples in {cpu_s:.1f} s, OpenMP team of {cpu_threads}; a stated baseline, not a target",
         }
     print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

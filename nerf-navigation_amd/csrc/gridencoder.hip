@@ -537,6 +537,9 @@ extern "C" int ngp_grid_encode_forward_rows(const float* inputs, const void* emb
     ge_fill_levels(lv, L, S, H);
     const dim3 grid_dim(ngp_div_up(B, 256)), block(256);
     const size_t lds = 256 * (size_t)(L + 1) * 2 * (dtype == NGP_F32 ? 4 : 2);
+    // 64 KiB is what a kernel gets without hipFuncSetAttribute(MaxDynamicSharedMemorySize): f32 tables up to 31 levels, f16 up to 32.
+    // gridencoder/grid.py sends larger ones to ngp_grid_encode_forward + permute (ngp_grid_encode_forward_rows_fits below is its test)
+    NGP_REQUIRE(lds <= 65536, "grid_encode_forward_rows: the row tile does not fit 64 KiB of LDS (use grid_encode_forward + a permute)");
     if (dtype == NGP_F32)
         hipLaunchKernelGGL(k_grid_forward_rows<float>, grid_dim, block, lds, (hipStream_t)stream, inputs, (const float*)embeddings, offsets, (float*)outputs,
                            B, L, lv, gridtype, align_corners != 0);

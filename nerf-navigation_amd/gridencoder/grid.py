@@ -81,7 +81,9 @@ class _grid_encode(Function):
         else:
             dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)
 
-        if ROWS_FORWARD and D == 3 and C == 2 and not (calc_grad_inputs and not recompute):
+        # the row kernel stages 256 x (L + 1) feature pairs in LDS: it takes tables whose tile fits the default 64 KiB (csrc/gridencoder.hip)
+        rows_fit = 256 * (L + 1) * 2 * embeddings.element_size() <= 65536
+        if ROWS_FORWARD and D == 3 and C == 2 and rows_fit and not (calc_grad_inputs and not recompute):
             # the reference's kernel writes [L, B, C] and grid.py:42,52 permutes + copies to [B, L*C]; this kernel writes the rows directly
             # (same bits): one launch and 2 x B x L x C values of traffic less per call
             outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)

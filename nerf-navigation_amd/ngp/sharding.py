@@ -4,10 +4,26 @@ import torch
 import torch.distributed as dist
 
 
+# True: take every collective even in a group of ONE rank (bench.py --force-dist, tests/test_gpu_rccl_single_rank.py): the only way a one-GPU box
+# can execute the RCCL calls of the N > 1 path.  A process group must be initialised.
+FORCE_COLLECTIVES = False
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def collectives_on():
+    """whether the collectives of the N > 1 path run: more than one rank, or forced on an initialised single-rank group"""
+    rank, ws = world()
+    return ws > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
+def barrier():
+    if collectives_on():
+        dist.barrier()
 
 
 def pose_indices(rank, world_size, n_poses):
@@ -28,8 +44,7 @@ def row_band(rank, world_size, height, align=8):
 
 def reduce_throughput(samples, seconds, device):
     """(sum over ranks of samples, max over ranks of seconds): the two scalars bench.py reports from."""
-    rank, ws = world()
-    if ws == 1:
+    if not collectives_on():
         return float(samples), float(seconds)
     s = torch.tensor([float(samples)], dtype=torch.float64, device=device)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
@@ -42,7 +57,7 @@ def gather_rows(local, device=None):
     """All-gather a [rows, ...] tensor of per-rank row bands into the full image on every rank (optional: the
     reference's eval loop gathers predictions the same way, nerf/utils.py:872-882)."""
     rank, ws = world()
-    if ws == 1:
+    if not collectives_on():
         return local
     sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(ws)]
     dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))

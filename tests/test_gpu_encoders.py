@@ -311,3 +311,26 @@ def test_grid_forward_rows_equals_level_major_plus_permute(dev, half):
     assert torch.equal(outs[True], outs[False])
     outside = ((x < -1) | (x > 1)).any(dim=-1)
     assert outside.sum() > 1000 and (outs[True][outside] == 0).all() and outs[True][~outside].abs().sum() > 0
+
+
+def test_grid_32_level_float32_table_takes_the_level_major_route(dev, oracle):
+    """a 32-level float32 table needs 256 x 33 x 8 B = 67,584 B of LDS in the row kernel, more than the 64 KiB a kernel gets by
+    default: the entry point refuses it (status code, no launch) and the module falls back to [L, B, C] + permute.  Values against the oracle."""
+    import gridencoder.grid as G
+    import ngp_hip
+    enc = G.GridEncoder(num_levels=32, log2_hashmap_size=12, base_resolution=4, desired_resolution=512).to(dev)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = torch.rand(5000, 3, device=dev) * 2 - 1
+    with torch.no_grad():
+        out = enc(x, bound=1)
+    assert out.shape == (5000, 64)
+    x01 = ((x + 1) / 2).cpu().numpy()
+    ref, _ = oracle.grid_encode_forward(x01, enc.embeddings.detach().cpu().numpy(), enc.offsets.cpu().numpy(), enc.per_level_scale, 4, False, 0, False)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), np.ascontiguousarray(ref.transpose(1, 0, 2).reshape(5000, 64)).view(np.uint32))
+    rows = torch.empty(5000, 64, device=dev)
+    rc = ngp_hip.lib().ngp_grid_encode_forward_rows(ngp_hip.ptr(x), ngp_hip.ptr(enc.embeddings.detach()), ngp_hip.ptr(enc.offsets), ngp_hip.ptr(rows), 5000, 3, 2, 32,
+                                                    float(np.log2(enc.per_level_scale)), 4, 0, 0, ngp_hip.F32, ngp_hip.stream())
+    assert rc != 0 and b"LDS" in ngp_hip.lib().ngp_last_error()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):                  # the half table of the same encoder fits (33,792 B): row kernel
+        assert enc(x, bound=1).shape == (5000, 64)
