@@ -677,3 +677,313 @@ extern "C" int ngp_grid_encode_backward_inputs(const void* grad, const float* in
     NGP_CHECK_LAUNCH("grid_encode_backward_inputs");
     return NGP_OK;
 }
+
+// =====================================================================================================================================
+// Binned scatter: the table gradient WITHOUT global atomics (D = 3, C = 2, half gradients -- the reference's hash grid under autocast).
+//
+// k_grid_backward issues one memory-side float atomic per (run of samples, corner): ~29 M 64-byte requests per 2 M-point step, executed
+// at the fabric at ~11 G requests/s whatever their locality (MI355X_MICROARCH.md "Global float atomics": nothing stays in L2) -- 2.7 ms,
+// half of a training step.  Here every contribution is summed ON CHIP instead:
+//   k_gs_bin         one 1,024-thread workgroup per (1,024 consecutive samples, level): the same arithmetic and the same wave-level run
+//                    aggregation as k_grid_backward, but a contribution becomes a 6-byte entry (row inside its slice: u16, value: half2)
+//                    that is counting-sorted by SLICE (a range of 16,384 or 4,096 table rows) in LDS and written out as one contiguous,
+//                    slice-ordered region plus a directory of slice offsets.  Plain coalesced stores, no atomics, no capacity guess:
+//                    a region has room for all 8,192 possible entries.
+//   k_gs_accumulate  persistent workgroups draw slices from a ticket counter; a slice's float32 accumulators (<= 128 KiB) live in LDS;
+//                    the workgroup walks every region's piece for its slice (16 lanes per piece, 64 pieces in flight per workgroup),
+//                    adds with ds_add_f32, and writes the finished rows ONCE, coalesced, as float32 or half -- the whole table is
+//                    written, so the destination needs no zero fill, and float32 output needs no widening copy afterwards.
+// Arithmetic: products w * grad summed over a run in binary32 and rounded to half (as k_grid_backward, gridencoder.cu:302); the sum over
+// entries is binary32 (the reference and k_grid_backward add in half: this is the more accurate of the two), rounded once on output.
+// Algorithmic bytes per point: 512 B of contributions (16 levels x 8 corners x 2 features x 2 B); traffic: 6 B per entry written and
+// read once (~1.8 entries per sample and level after run aggregation on a training batch) + 76 B per sample read + the table written once.
+// =====================================================================================================================================
+static constexpr uint32_t GS_CHUNK = 1024;            // samples per region = threads per k_gs_bin workgroup
+static constexpr uint32_t GS_REGION = GS_CHUNK * 8;   // entries a region can hold (every corner of every sample)
+static constexpr uint32_t GS_MAX_SLICES = 64;         // slices per level (directory rows: GS_MAX_SLICES + 1)
+static constexpr uint32_t GS_SLICE_ROWS = 8192;       // rows per slice of a large level (2 x 64-bit fixed-point accumulators per row = 128 KiB of LDS)
+static constexpr uint32_t GS_PASS_SAMPLES = 1u << 21; // samples per pass (bounds the workspace at 1.6 GB; more samples = more passes)
+static int gs_debug_flags = 0;                         // timing experiments only (ngp_grid_scatter_debug): 1 = no LDS adds, 2 = no entry loads, 4 = padded region stride
+extern "C" int ngp_grid_scatter_debug(int flags) { gs_debug_flags = flags; return NGP_OK; }
+static uint32_t gs_stride() { return GS_REGION + ((gs_debug_flags & 4) ? 96u : 0u); }
+
+// rows per slice as a shift: levels of up to 2^18 rows are cut into 4,096-row slices so that the few, heavily hit rows of the coarse
+// levels spread over several workgroups; larger (hashed) levels into 8,192-row slices so that a region's piece per slice stays long
+__device__ __forceinline__ uint32_t gs_shift(uint32_t level_rows) { return level_rows > (1u << 18) ? 13u : 12u; }
+
+// A half as a 64-bit fixed-point number in units of 2^-24 (the smallest half subnormal): EXACT for every finite half (|q| < 2^40), so
+// the sum of up to 2^22 entries is exact in 64 bits and does not depend on the order of the adds -- the LDS adds are integer adds
+// (ds_add_u64: ~15 cycles per 64 lanes on gfx950, measured; ds_add_f32 / ds_pk_add_f16 serialise at ~195-390: tools/micro/lds_atomics.hip).
+// Returns false for inf / NaN (a GradScaler overflow): the caller poisons the slice instead.
+__device__ __forceinline__ bool gs_half_to_fixed(uint32_t bits, long long& q) {
+    const uint32_t e = (bits >> 10) & 31u, m = bits & 1023u;
+    const unsigned long long mag = e ? ((unsigned long long)(1024u | m) << (e - 1u)) : (unsigned long long)m;
+    q = (bits & 0x8000u) ? -(long long)mag : (long long)mag;
+    return e != 31u;
+}
+
+struct gs_ws {                                         // workspace layout (byte offsets), computed on the host
+    size_t vals, rows, dir, ticket, total;
+    uint32_t nchunks;
+};
+
+static gs_ws gs_layout(uint32_t B, uint32_t L) {
+    gs_ws w;
+    const uint32_t b = B < GS_PASS_SAMPLES ? B : GS_PASS_SAMPLES;
+    w.nchunks = ngp_div_up(b, GS_CHUNK);
+    const size_t regions = (size_t)L * w.nchunks;
+    w.ticket = 0;                                      // [1] u32 (+ padding to 256 B)
+    w.dir = 256;                                       // [L][GS_MAX_SLICES + 1][nchunks] u16
+    w.vals = w.dir + (((size_t)L * (GS_MAX_SLICES + 1) * w.nchunks * 2 + 255) & ~(size_t)255);   // [L][nchunks][GS_REGION] u32
+    w.rows = w.vals + regions * (GS_REGION + 96) * 4;                                           // [L][nchunks][GS_REGION] u16
+    w.total = w.rows + regions * (GS_REGION + 96) * 2;
+    return w;
+}
+
+__global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
+                                                 uint32_t* __restrict__ g_vals, uint16_t* __restrict__ g_rows, uint16_t* __restrict__ g_dir,
+                                                 uint32_t B, uint32_t first, uint32_t count, uint32_t nchunks, ge_levels lv, uint32_t gridtype,
+                                                 bool align_corners, uint32_t stride) {
+    __shared__ uint32_t s_vals[GS_REGION];             // 32 KiB: the region, slice-sorted
+    __shared__ uint16_t s_rows[GS_REGION];             // 16 KiB
+    __shared__ uint32_t s_hist[GS_MAX_SLICES + 1];     // entries per slice, then (after the scan) first entry of each slice
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    constexpr uint32_t D = 3;
+    const uint32_t tid = threadIdx.x, chunk = blockIdx.x, level = blockIdx.y;
+    const uint32_t i = chunk * GS_CHUNK + tid;         // sample inside this pass
+    bool valid = i < count;
+    const uint32_t b = first + (valid ? i : 0u);
+    const uint32_t level_rows = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t shift = gs_shift(level_rows);
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    if (tid <= GS_MAX_SLICES) s_hist[tid] = 0u;
+
+    float pos[D];
+    uint32_t pg[D];
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float x = inputs[(uint64_t)b * D + d];
+        if (x < 0 || x > 1) valid = false;             // out of range: contributes nothing (gridencoder.cu:251-258)
+        pos[d] = x * scale + (align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    const h2 gin = *reinterpret_cast<const h2*>(grad + ((uint64_t)level * B + b) * 2);
+    const float g0 = valid ? (float)gin.x : 0.0f, g1 = valid ? (float)gin.y : 0.0f;
+
+    // runs of consecutive lanes in the same cell (consecutive samples of a ray): summed across the run, the last lane emits
+    const int lane = (int)(tid & 63u);
+    bool same = valid && lane > 0 && __shfl_up((int)valid, 1, 64) != 0;
+    #pragma unroll
+    for (uint32_t d = 0; d < D; d++) same = (__shfl_up(pg[d], 1, 64) == pg[d]) && same;
+    const unsigned long long heads = __ballot(!same);
+    const int start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    const bool merge = heads != ~0ull;                 // wave-uniform: false on the fine levels, where every sample sits in a cell of its own
+    __syncthreads();                                   // s_hist is zero
+
+    uint32_t e_val[8], e_key[8], e_rank[8];
+    #pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float wi = 1;
+        uint32_t pl[D];
+        #pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { wi *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { wi *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        float v0 = wi * g0, v1 = wi * g1;
+        if (merge) {
+            #pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o0 = __shfl_up(v0, off, 64), o1 = __shfl_up(v1, off, 64);
+                if (lane - off >= start) { v0 += o0; v1 += o1; }
+            }
+        }
+        const bool send = tail && valid && !(v0 == 0.0f && v1 == 0.0f);
+        const uint32_t row = ge_index<D>(gridtype, align_corners, level_rows, resolution, pl);
+        h2 hv;
+        hv.x = ngp_f2h(v0);
+        hv.y = ngp_f2h(v1);
+        e_val[idx] = __builtin_bit_cast(uint32_t, hv);
+        uint32_t slice = row >> shift;
+        if (slice >= GS_MAX_SLICES) slice = GS_MAX_SLICES - 1;                              // (never for levels of <= 2^20 rows; the host checks)
+        e_key[idx] = send ? ((slice << 16) | (row - (slice << shift))) : 0xFFFFFFFFu;
+        e_rank[idx] = send ? atomicAdd(&s_hist[slice], 1u) : 0u;                            // ds_add_rtn_u32: the entry's rank inside its slice
+    }
+    __syncthreads();
+    if (tid < 64) {                                    // exclusive scan of the 64 slice counts by one wave
+        const uint32_t c = s_hist[tid];
+        uint32_t incl = c;
+        #pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if ((int)tid >= off) incl += o;
+        }
+        s_hist[tid] = incl - c;
+        if (tid == 63) s_hist[64] = incl;
+    }
+    __syncthreads();
+    #pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        if (e_key[idx] != 0xFFFFFFFFu) {
+            const uint32_t p = s_hist[e_key[idx] >> 16] + e_rank[idx];
+            s_vals[p] = e_val[idx];
+            s_rows[p] = (uint16_t)(e_key[idx] & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_hist[64];
+    const size_t region = ((size_t)level * nchunks + chunk) * stride;
+    for (uint32_t k = tid; k < total; k += GS_CHUNK) g_vals[region + k] = s_vals[k];
+    uint32_t* rows32 = reinterpret_cast<uint32_t*>(g_rows + region);
+    const uint32_t* s_rows32 = reinterpret_cast<const uint32_t*>(s_rows);
+    for (uint32_t k = tid; k < (total + 1) / 2; k += GS_CHUNK) rows32[k] = s_rows32[k];
+    if (tid <= GS_MAX_SLICES) g_dir[((size_t)level * (GS_MAX_SLICES + 1) + tid) * nchunks + chunk] = (uint16_t)s_hist[tid];
+}
+
+// the (level, slice) of ticket t, levels from the finest down so that the large hashed levels start first.  Evaluated by one wave: lane l
+// holds level L-1-l (L <= 32), an inclusive scan of the slice counts finds the level in one step instead of a 16-deep chain of loads.
+__device__ __forceinline__ uint32_t gs_decode_wave(const int* __restrict__ offsets, uint32_t L, uint32_t t, uint32_t lane) {
+    uint32_t n = 0;
+    const int l = (int)L - 1 - (int)lane;
+    if (l >= 0) {
+        const uint32_t rows = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const uint32_t sh = gs_shift(rows);
+        n = (rows + (1u << sh) - 1) >> sh;
+        if (n > GS_MAX_SLICES) n = GS_MAX_SLICES;
+    }
+    uint32_t incl = n;
+    #pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += o;
+    }
+    const unsigned long long hit = __ballot(l >= 0 && t < incl);     // first lane whose inclusive count exceeds t
+    if (hit == 0ull) return 0xFFFFFFFFu;
+    const int first = __ffsll((long long)hit) - 1;
+    const uint32_t before = __shfl(incl - n, first, 64);
+    return ((uint32_t)((int)L - 1 - first) << 16) | (t - before);
+}
+
+template <typename OUT_T>
+__global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restrict__ g_vals, const uint16_t* __restrict__ g_rows,
+                                                        const uint16_t* __restrict__ g_dir, const int* __restrict__ offsets, uint32_t* ticket,
+                                                        OUT_T* __restrict__ out, uint32_t L, uint32_t nchunks, float out_scale, bool add_to_out,
+                                                        uint32_t stride, int dbg) {
+    extern __shared__ unsigned long long s_acc[];      // [GS_SLICE_ROWS][2] 64-bit fixed point (units of 2^-24)
+    __shared__ uint32_t s_ticket, s_poison;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, sub = lane >> 4, l16 = lane & 15u;
+    for (;;) {
+        __syncthreads();                               // the previous slice is written out; s_ticket may be overwritten
+        if (wave == 0) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(ticket, 1u);
+            t = __shfl(t, 0, 64);
+            const uint32_t code = gs_decode_wave(offsets, L, t, lane);
+            if (lane == 0) { s_ticket = code; s_poison = 0u; }
+        }
+        __syncthreads();
+        if (s_ticket == 0xFFFFFFFFu) return;
+        const uint32_t level = s_ticket >> 16, slice = s_ticket & 0xFFFFu;
+        const uint32_t level_rows = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const uint32_t shift = gs_shift(level_rows);
+        const uint32_t row0 = slice << shift;
+        uint32_t nrows = level_rows - row0;
+        if (nrows > (1u << shift) && slice + 1 < GS_MAX_SLICES) nrows = 1u << shift;
+        if (nrows > GS_SLICE_ROWS) nrows = GS_SLICE_ROWS;                                   // (rows beyond were never binned here: host check)
+        for (uint32_t k = tid; k < nrows * 2; k += 1024) s_acc[k] = 0ull;
+        __syncthreads();
+        const uint16_t* dir0 = g_dir + ((size_t)level * (GS_MAX_SLICES + 1) + slice) * nchunks;
+        const uint16_t* dir1 = dir0 + nchunks;
+        // a wave-iteration = 4 regions, 16 lanes per region's piece; iterations are dealt round-robin to the 16 waves (every wave busy for any
+        // number of regions); the directory entry of the NEXT iteration is loaded before this one's entries are consumed
+        const uint32_t n_it = (nchunks + 3) / 4;
+        uint32_t off = 0, cnt = 0;
+        if (wave < n_it) { const uint32_t r = wave * 4 + sub; if (r < nchunks) { off = dir0[r]; cnt = (uint32_t)dir1[r] - off; } }
+        for (uint32_t it = wave; it < n_it; it += 16) {
+            const uint32_t o = off, c = cnt, r = it * 4 + sub;
+            off = 0; cnt = 0;
+            if (it + 16 < n_it) { const uint32_t rn = (it + 16) * 4 + sub; if (rn < nchunks) { off = dir0[rn]; cnt = (uint32_t)dir1[rn] - off; } }
+            const size_t base = ((size_t)level * nchunks + r) * stride + o;
+            for (uint32_t k = l16; k < c; k += 32) {
+                const bool two = k + 16 < c;
+                const uint32_t va = (dbg & 2) ? k : g_vals[base + k], ra = (dbg & 2) ? (k * 37u) & 4095u : g_rows[base + k];
+                const uint32_t vb = two ? g_vals[base + k + 16] : 0u, rb = two ? g_rows[base + k + 16] : 0xFFFFu;
+                long long q0, q1, q2, q3;
+                const bool fa = gs_half_to_fixed(va & 0xFFFFu, q0), fb = gs_half_to_fixed(va >> 16, q1);
+                const bool fc = gs_half_to_fixed(vb & 0xFFFFu, q2), fd = gs_half_to_fixed(vb >> 16, q3);
+                if (!(fa && fb && fc && fd)) s_poison = 1u;
+                else if (!(dbg & 1)) {
+                    if (ra < nrows) {
+                        atomicAdd(&s_acc[2 * ra], (unsigned long long)q0);                  // ds_add_u64, no return
+                        atomicAdd(&s_acc[2 * ra + 1], (unsigned long long)q1);
+                    }
+                    if (rb < nrows) {
+                        atomicAdd(&s_acc[2 * rb], (unsigned long long)q2);
+                        atomicAdd(&s_acc[2 * rb + 1], (unsigned long long)q3);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        OUT_T* dst = out + ((size_t)(uint32_t)offsets[level] + row0) * 2;
+        const bool poison = s_poison != 0u;            // an inf / NaN contribution (loss-scale overflow): the slice reports NaN, the step is skipped
+        for (uint32_t k = tid; k < nrows * 2; k += 1024) {
+            double v = (double)(long long)s_acc[k] * (1.0 / 16777216.0) * (double)out_scale;   // exact sum, one rounding on output
+            if (add_to_out) v += (double)(float)dst[k];
+            dst[k] = poison ? (OUT_T)__builtin_nanf("") : (OUT_T)(float)v;
+        }
+    }
+}
+
+extern "C" size_t ngp_grid_scatter_binned_workspace(uint32_t B, uint32_t L) {
+    return gs_layout(B, L).total;
+}
+
+extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                       uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
+                                       int out_dtype, float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(offsets && grad_embeddings && (B == 0 || (grad && inputs)), "grid_scatter_binned: null pointer");
+    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_scatter_binned: L must be in 1..32");
+    NGP_REQUIRE(out_dtype == NGP_F32 || out_dtype == NGP_F16, "grid_scatter_binned: out_dtype must be f32 or f16");
+    NGP_REQUIRE(max_level_rows >= 1 && max_level_rows <= GS_MAX_SLICES * GS_SLICE_ROWS,
+                "grid_scatter_binned: a level may have at most 2^19 rows (use grid_encode_backward for larger tables)");
+    const gs_ws w = gs_layout(B, L);
+    NGP_REQUIRE(workspace && workspace_bytes >= w.total, "grid_scatter_binned: workspace too small (see ngp_grid_scatter_binned_workspace)");
+    hipStream_t s = (hipStream_t)stream;
+    ge_levels lv;
+    ge_fill_levels(lv, L, S, H);
+    char* base = (char*)workspace;
+    static bool lds_ok = false;
+    const size_t lds = (size_t)GS_SLICE_ROWS * 2 * sizeof(unsigned long long);
+    if (!lds_ok) {
+        if (hipFuncSetAttribute((const void*)k_gs_accumulate<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_gs_accumulate<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ngp_fail(NGP_ELAUNCH, "grid_scatter_binned: cannot reserve %zu bytes of LDS", lds);
+        lds_ok = true;
+    }
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; }
+    uint32_t first = 0;
+    bool add = false;
+    do {                                               // B == 0: one pass that writes zeros (the whole table is always written)
+        const uint32_t count = B - first < GS_PASS_SAMPLES ? B - first : GS_PASS_SAMPLES;
+        const uint32_t nchunks = count ? ngp_div_up(count, GS_CHUNK) : 0u;
+        if (hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "grid_scatter_binned: memset failed");
+        if (nchunks)
+            hipLaunchKernelGGL(k_gs_bin, dim3(nchunks, L), dim3(GS_CHUNK), 0, s, (const _Float16*)grad, inputs, offsets, (uint32_t*)(base + w.vals),
+                               (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0, gs_stride());
+        if (out_dtype == NGP_F32)
+            hipLaunchKernelGGL(k_gs_accumulate<float>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
+                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (float*)grad_embeddings, L, nchunks, out_scale, add, gs_stride(), gs_debug_flags);
+        else
+            hipLaunchKernelGGL(k_gs_accumulate<_Float16>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
+                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (_Float16*)grad_embeddings, L, nchunks, out_scale, add, gs_stride(), gs_debug_flags);
+        first += count;
+        add = true;
+    } while (first < B);
+    NGP_CHECK_LAUNCH("grid_scatter_binned");
+    return NGP_OK;
+}

@@ -23,6 +23,10 @@ RECOMPUTE_INPUT_GRAD = True
 # ... from this many points on: the recomputing kernel walks the levels of a point in one lane (that keeps the reference's
 # summation order), so a small batch (the planner's 10,000 body points) does not fill the chip and is faster with dy_dx
 RECOMPUTE_MIN_POINTS = 32768
+# True: the table gradient of a half D = 3, C = 2 grid (the reference's hash grid under autocast) is summed on chip by the binned scatter
+# (ngp_grid_scatter_binned: no global atomics, float32 sums, float32 output = the parameter's dtype, no zero fill, no widening copy).
+# False: the reference's route, half2 atomics into a zero-filled half table (ngp_grid_encode_backward).
+BINNED_SCATTER = True
 # True: D = 3, C = 2 forwards write [B, L*C] directly (ngp_grid_encode_forward_rows) instead of [L, B, C] + permute copy.  Same bits.
 ROWS_FORWARD = True
 
@@ -50,6 +54,36 @@ def _half_table(embeddings, training):
     half = embeddings.detach().to(torch.half)
     embeddings._ngp_half = (embeddings._version, embeddings.data_ptr(), half)
     return half
+
+
+_MAX_ROWS = {}
+
+
+def offsets_info(offsets):
+    """(largest number of rows of any level, rows of the whole table): one host read per offsets tensor, cached on its storage pointer"""
+    key = (offsets.data_ptr(), offsets.numel(), str(offsets.device))
+    if key not in _MAX_ROWS:
+        o = offsets.detach().cpu().to(torch.int64)
+        _MAX_ROWS[key] = (int((o[1:] - o[:-1]).max()), int(o[-1]))
+    return _MAX_ROWS[key]
+
+
+def offsets_max_rows(offsets):
+    return offsets_info(offsets)[0]
+
+
+def table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, align_corners, out_dtype=torch.float32, out_scale=1.0):
+    """grad [L,B,2] half (level-major), inputs [B,3] float32 in [0,1] -> the table gradient [sO,2] in `out_dtype`, summed on chip
+    (ngp_grid_scatter_binned).  Shared by _grid_encode.backward and the field's native training step (ngp/field.py)."""
+    lib = _hip.lib()
+    rows, n = offsets_info(offsets)
+    out = torch.empty(n, 2, dtype=out_dtype, device=inputs.device)
+    ws = _hip.workspace(lib.ngp_grid_scatter_binned_workspace(B, L), inputs.device)
+    with _hip.timed("grid_encode_backward"):
+        _hip.check(lib.ngp_grid_scatter_binned(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), B, L, float(S), H, rows, gridtype,
+                                               int(align_corners), _hip.dtype_code(out_dtype), float(out_scale), _hip.ptr(ws), ws.numel(), _hip.stream()),
+                   "grid_scatter_binned")
+    return out
 
 
 class _grid_encode(Function):
@@ -118,16 +152,20 @@ class _grid_encode(Function):
         need_table = ctx.needs_input_grad[1]
         if not need_table and not calc_grad_inputs:
             return None, None, None, None, None, None, None, None
-        grad_embeddings = torch.zeros_like(embeddings) if need_table else None
+        binned = (BINNED_SCATTER and need_table and D == 3 and C == 2 and embeddings.dtype == torch.float16
+                  and int(offsets_max_rows(offsets)) <= (1 << 19))
+        grad_embeddings = None
+        if need_table:
+            grad_embeddings = table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, ctx.align_corners) if binned else torch.zeros_like(embeddings)
         if calc_grad_inputs:
             grad_inputs = (torch.empty_like if ctx.recompute else torch.zeros_like)(inputs, dtype=embeddings.dtype)
         else:
             grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
 
-        if need_table or not ctx.recompute:
+        if (need_table and not binned) or (calc_grad_inputs and not ctx.recompute):
             with _hip.timed("grid_encode_backward"):
                 _hip.check(_hip.lib().ngp_grid_encode_backward(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(embeddings), _hip.ptr(offsets),
-                                                               _hip.ptr(grad_embeddings) if need_table else None, B, D, C, L, float(S), H,
+                                                               _hip.ptr(grad_embeddings) if (need_table and not binned) else None, B, D, C, L, float(S), H,
                                                                int(calc_grad_inputs and not ctx.recompute),
                                                                _hip.ptr(dy_dx), _hip.ptr(grad_inputs), gridtype, int(ctx.align_corners),
                                                                _hip.dtype_code(embeddings.dtype), _hip.stream()), "grid_encode_backward")

@@ -100,14 +100,21 @@ class _field_train(Function):
                    "field_train_backward")
         grad_emb = None
         if ctx.needs_input_grad[2]:
+            from gridencoder import grid as G
             inputs = ((x + field.bound) / (2 * field.bound)).contiguous()          # GridEncoder.forward (gridencoder/grid.py:144)
-            grad_emb = torch.zeros_like(emb_half)
-            dummy = torch.empty(1, dtype=torch.float16, device=x.device)
-            with _hip.timed("grid_encode_backward"):
-                _hip.check(L.ngp_grid_encode_backward(_hip.ptr(grad_enc), _hip.ptr(inputs), _hip.ptr(emb_half), _hip.ptr(enc.offsets), _hip.ptr(grad_emb),
-                                                      M, 3, enc.level_dim, enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, 0,
-                                                      _hip.ptr(dummy), _hip.ptr(dummy), enc.gridtype_id, int(enc.align_corners), _hip.F16, _hip.stream()),
-                           "grid_encode_backward")
+            S = float(np.log2(enc.per_level_scale))
+            if G.BINNED_SCATTER and G.offsets_max_rows(enc.offsets) <= (1 << 19):
+                # summed on chip in float32 and written as the float32 gradient of the float32 parameter: no zero fill, no atomics, no widening
+                grad_emb = G.table_gradient_binned(grad_enc, inputs, enc.offsets, M, enc.num_levels, S, enc.base_resolution, enc.gridtype_id,
+                                                   enc.align_corners)
+            else:
+                grad_emb = torch.zeros_like(emb_half)
+                dummy = torch.empty(1, dtype=torch.float16, device=x.device)
+                with _hip.timed("grid_encode_backward"):
+                    _hip.check(L.ngp_grid_encode_backward(_hip.ptr(grad_enc), _hip.ptr(inputs), _hip.ptr(emb_half), _hip.ptr(enc.offsets), _hip.ptr(grad_emb),
+                                                          M, 3, enc.level_dim, enc.num_levels, S, enc.base_resolution, 0,
+                                                          _hip.ptr(dummy), _hip.ptr(dummy), enc.gridtype_id, int(enc.align_corners), _hip.F16, _hip.stream()),
+                               "grid_encode_backward")
         return None, None, grad_emb, g_ws, g_wc, None
 
 
