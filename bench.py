@@ -100,7 +100,7 @@ def bench_train(args, rank, world, dev, W, teacher):
         pool.append((to, td, teacher.render_fused(to, td, bg_color=1, image_width=res)["image"]))
     torch.manual_seed(0)                                                    # identical initial replicas
     student = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
-    tr = NGPTrainer(student, lr=1e-2, iters=30000, fp16=True)
+    tr = NGPTrainer(student, lr=1e-2, iters=30000, fp16=True, steps_per_epoch=len(pool), time_exchange=True)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
 
     def step(k):
@@ -142,22 +142,21 @@ def bench_train(args, rank, world, dev, W, teacher):
     rays_all, t_max = sharding.reduce_throughput(n_rays * args.steps, elapsed, dev)
     if rank == 0:
         def roof(pts, ms, profiled_phase=False):
+            """the table-gradient scatter (binned: k_gs_bin + k_gs_accumulate, event-timed together): 512 algorithmic bytes of contributions per
+            point against HBM (no atomics left: the bound is the entry traffic), with the float-atomic peak the replaced kernel was priced at beside it"""
             if not ms:
                 return None
             a = SCATTER_BYTES_PER_POINT * pts / (ms * 1e-3) / 1e9
-            r = {"bound": "atomic", "kernel": "k_grid_backward<half,3,2>", "achieved": a, "peak": ATOMIC_PEAK_GBS, "unit": "GB/s",
-                 "frac": a / ATOMIC_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+            r = {"bound": "hbm", "kernel": "k_gs_bin + k_gs_accumulate (binned scatter, csrc/gridencoder.hip)", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": a / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
                  "algorithmic_bytes_per_point": SCATTER_BYTES_PER_POINT, "points_per_launch": pts,
-                 # the 1.3 TB/s peak is for 256 contiguous bytes per wave instruction; a hash-grid scatter is one 64-byte request per lane pair
-                 # (the guide: "64 lanes in 64 different rows ~17x slower"), i.e. ~20 G requests/s chip-wide is the ceiling that applies
-                 "scattered_request_peak_G_per_s": 20.0}
+                 "vs_float_atomic_peak": a / ATOMIC_PEAK_GBS, "float_atomic_peak_GBs": ATOMIC_PEAK_GBS,
+                 "replaced": "k_grid_backward<half,3,2>: 2.68 ms at 2.0 M points (profiles/r14_train), 0.29-0.39 of the atomic peak"}
             c, info = committed_counters("r[0-9][0-9]_train_pmc.csv", TRAIN_SOURCES)
-            if c is not None and c.get("WRITE_SIZE"):
+            if c is not None and c.get("WRITE_SIZE") and profiled_phase:   # the committed profile was collected on the early grid: the warm-up phase's launches
                 r["profile"] = info["profile"]
-                r["profiled_requests_per_launch"] = c["WRITE_SIZE"] * 1024.0 / 64.0
-                if profiled_phase:                 # profiles/r14_train was collected on the early grid: its bytes belong to the warm-up phase's launches
-                    r["traffic"] = (c["WRITE_SIZE"] + c.get("FETCH_SIZE", 0.0)) * 1024.0
-                    r["traffic_unit"] = "bytes per launch, fabric side (every atomic request is a 32-byte write; L2 hit rate 0.007)"
+                r["traffic"] = (c["WRITE_SIZE"] + c.get("FETCH_SIZE", 0.0)) * 1024.0
+                r["traffic_unit"] = "bytes per launch of k_gs_bin alone, fabric side (profiles/*_train_pmc.csv lists the first-named kernel)"
             return r
         print(json.dumps({
             "metric": "training rays/sec (4096-ray steps, FFMLP field under autocast, Adam, grid refresh every 16 steps)",
@@ -166,7 +165,13 @@ def bench_train(args, rank, world, dev, W, teacher):
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"S-{args.workload} training (teacher-rendered 200x200 views), native field forward + backward, march, composite and table scatter under autograd, steady state after "
                                    f"{args.warmup + args.steps + args.settle} steps",
-                       "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": loss},
+                       "rays_per_step_per_gpu": n_rays, "points_per_step": points, "final_loss": loss,
+                       "collectives": ("nccl (RCCL)" if dist.is_initialized() and dist.get_backend() == "nccl" else ("gloo rehearsal" if dist.is_initialized() else "none (one process)"))
+                                      + (", forced on a single rank" if args.force_dist and world == 1 else "")},
+            # gradient exchange of the LAST step: bytes handed to all-reduce (half table + float32 weight bucket on the native route) and the GPU time
+            # between the end of the backward and the gradients being ready (events on the compute stream); zero / null without a process group
+            "allreduce_bytes": tr.exchange.stats["allreduce_bytes"], "exposed_collective_ms": tr.exchange.exposed_ms(),
+            "weight_ema": {"decay": 0.95, "updates": tr.ema.num_updates, "every_steps": len(pool)},
             "roofline": roof(points, scatter_ms),
             "warmup_phase": {"ms_per_step": 1e3 * warm[0] / args.steps, "points_per_step": warm[2], "loss": warm[1],
                              "roofline": roof(warm[2], warm[3], profiled_phase=True)}}))
@@ -190,7 +195,7 @@ def fit_model(args, dev, W, teacher):
         pool.append((to, td, teacher.render_fused(to, td, bg_color=1, image_width=res)["image"]))
     torch.manual_seed(0)
     student = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
-    tr = NGPTrainer(student, lr=1e-2, iters=args.fit_steps, fp16=True)
+    tr = NGPTrainer(student, lr=1e-2, iters=args.fit_steps, fp16=True, steps_per_epoch=len(pool))       # 24 views = one epoch: the weight average follows
     gen = torch.Generator(device=dev).manual_seed(1)
     t0 = time.perf_counter()
     for k in range(args.fit_steps):
@@ -198,12 +203,21 @@ def fit_model(args, dev, W, teacher):
         idx = torch.randint(0, res * res, (n_rays,), device=dev, generator=gen)
         loss = tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=1024)
     torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
     student.eval()
+    to, td, tc = pool[1]
     with torch.no_grad():
-        to, td, tc = pool[1]
+        live = float(-10 * torch.log10(torch.mean((student.render_fused(to, td, bg_color=1, image_width=res)["image"] - tc) ** 2)))
+    # the reference evaluates (and saves its best checkpoint) with the exponential moving average of the weights (nerf/utils.py:851-853,
+    # :983-994): install it for everything that follows -- the timed renders and the PSNR legs of the bench
+    tr.ema.store()
+    tr.ema.copy_to()
+    student.field.mark_updated()
+    with torch.no_grad():
         img = student.render_fused(to, td, bg_color=1, image_width=res)["image"]
         psnr = float(-10 * torch.log10(torch.mean((img - tc) ** 2)))
-    return student, {"steps": args.fit_steps, "seconds": time.perf_counter() - t0, "final_loss": float(loss), "psnr_vs_teacher_db": psnr,
+    return student, {"steps": args.fit_steps, "seconds": seconds, "final_loss": float(loss), "psnr_vs_teacher_db": psnr,
+                     "weights": f"exponential moving average (decay 0.95, {tr.ema.num_updates} epoch updates), as the reference evaluates", "psnr_live_weights_db": live,
                      "occupied_cells": int(torch.count_nonzero(student.density_grid > min(student.mean_density, 10.0)))}
 
 

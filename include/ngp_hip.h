@@ -202,10 +202,10 @@ int ngp_grid_encode_backward_inputs(const void* grad, const float* inputs, const
                                     void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, void* stream);
 
 /* The table gradient of grid_encode_backward for the reference's hash grid under autocast (D = 3, C = 2, half `grad` [L,B,2]) WITHOUT
- * global atomics (gridencoder.cu:227-314 scatters with atomicAdd(__half2)): contributions are binned by table slice and summed in LDS in
- * float32 (csrc/gridencoder.hip "Binned scatter").  grad_embeddings [sO,2] is WRITTEN WHOLE (no pre-zeroing), as float32 or half
+ * global atomics (gridencoder.cu:227-314 scatters with atomicAdd(__half2)): contributions are binned by table slice and summed in LDS, exactly, as
+ * 64-bit fixed point (csrc/gridencoder.hip "Binned scatter").  grad_embeddings [sO,2] is WRITTEN WHOLE (no pre-zeroing), as float32 or half
  * (`out_dtype`), multiplied by out_scale.  max_level_rows: an upper bound of the rows of any level (2^log2_hashmap_size), at most 2^19.
- * workspace: ngp_grid_scatter_binned_workspace(B, L) bytes (1.6 GB from 2^21 samples on: more samples run in passes). */
+ * workspace: ngp_grid_scatter_binned_workspace(B, L) bytes (768 B per sample, at most 3.2 GB: from 2^22 samples on the call runs in passes). */
 size_t ngp_grid_scatter_binned_workspace(uint32_t B, uint32_t L);
 int ngp_grid_scatter_binned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                             uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,

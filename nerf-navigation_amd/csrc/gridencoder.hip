@@ -689,23 +689,26 @@ extern "C" int ngp_grid_encode_backward_inputs(const void* grad, const float* in
 //                    that is counting-sorted by SLICE (a range of 16,384 or 4,096 table rows) in LDS and written out as one contiguous,
 //                    slice-ordered region plus a directory of slice offsets.  Plain coalesced stores, no atomics, no capacity guess:
 //                    a region has room for all 8,192 possible entries.
-//   k_gs_accumulate  persistent workgroups draw slices from a ticket counter; a slice's float32 accumulators (<= 128 KiB) live in LDS;
-//                    the workgroup walks every region's piece for its slice (16 lanes per piece, 64 pieces in flight per workgroup),
-//                    adds with ds_add_f32, and writes the finished rows ONCE, coalesced, as float32 or half -- the whole table is
-//                    written, so the destination needs no zero fill, and float32 output needs no widening copy afterwards.
+//   k_gs_accumulate  persistent workgroups draw slices from a ticket counter; a slice's accumulators (<= 128 KiB) live in LDS as 64-BIT
+//                    FIXED POINT in units of 2^-24, in which every finite half is an integer: the sum of a slice's entries is EXACT and
+//                    independent of the order of the adds (bitwise reproducible), and the adds are integer LDS atomics -- ds_add_u64 runs
+//                    at ~15 cycles per 64 lanes on gfx950 while ds_add_f32 / ds_pk_add_f16 serialise at ~390 / ~195 (measured:
+//                    tools/micro/lds_atomics.hip; a float32 version of this kernel spent 3.9 of its 4.4 ms in them).  The workgroup walks
+//                    every region's piece for its slice (16 lanes per piece, 64 pieces in flight), and writes the finished rows ONCE,
+//                    coalesced, as float32 or half -- the whole table is written, so the destination needs no zero fill, and float32
+//                    output needs no widening copy afterwards.  An inf / NaN entry (loss-scale overflow) poisons its slice with NaN.
 // Arithmetic: products w * grad summed over a run in binary32 and rounded to half (as k_grid_backward, gridencoder.cu:302); the sum over
-// entries is binary32 (the reference and k_grid_backward add in half: this is the more accurate of the two), rounded once on output.
+// entries is exact (the reference and k_grid_backward add in half, in arbitrary order), rounded once on output.
 // Algorithmic bytes per point: 512 B of contributions (16 levels x 8 corners x 2 features x 2 B); traffic: 6 B per entry written and
-// read once (~1.8 entries per sample and level after run aggregation on a training batch) + 76 B per sample read + the table written once.
+// read once (~58 entries per point on a training batch: runs merge on the coarse levels only) + 76 B per sample read + the table written once.
+// Measured (profiles/r15_train, 1.8 M points): k_gs_bin 0.71 + k_gs_accumulate 0.65 ms per step against 2.68 ms for k_grid_backward.
 // =====================================================================================================================================
 static constexpr uint32_t GS_CHUNK = 1024;            // samples per region = threads per k_gs_bin workgroup
 static constexpr uint32_t GS_REGION = GS_CHUNK * 8;   // entries a region can hold (every corner of every sample)
 static constexpr uint32_t GS_MAX_SLICES = 64;         // slices per level (directory rows: GS_MAX_SLICES + 1)
 static constexpr uint32_t GS_SLICE_ROWS = 8192;       // rows per slice of a large level (2 x 64-bit fixed-point accumulators per row = 128 KiB of LDS)
-static constexpr uint32_t GS_PASS_SAMPLES = 1u << 21; // samples per pass (bounds the workspace at 1.6 GB; more samples = more passes)
-static int gs_debug_flags = 0;                         // timing experiments only (ngp_grid_scatter_debug): 1 = no LDS adds, 2 = no entry loads, 4 = padded region stride
-extern "C" int ngp_grid_scatter_debug(int flags) { gs_debug_flags = flags; return NGP_OK; }
-static uint32_t gs_stride() { return GS_REGION + ((gs_debug_flags & 4) ? 96u : 0u); }
+static constexpr uint32_t GS_PASS_SAMPLES = 1u << 22; // samples per pass: one pass for any 4,096-ray x 1,024-step training batch (workspace <= 3.2 GB;
+                                                       // more samples run in further passes that add into the output)
 
 // rows per slice as a shift: levels of up to 2^18 rows are cut into 4,096-row slices so that the few, heavily hit rows of the coarse
 // levels spread over several workgroups; larger (hashed) levels into 8,192-row slices so that a region's piece per slice stays long
@@ -735,15 +738,15 @@ static gs_ws gs_layout(uint32_t B, uint32_t L) {
     w.ticket = 0;                                      // [1] u32 (+ padding to 256 B)
     w.dir = 256;                                       // [L][GS_MAX_SLICES + 1][nchunks] u16
     w.vals = w.dir + (((size_t)L * (GS_MAX_SLICES + 1) * w.nchunks * 2 + 255) & ~(size_t)255);   // [L][nchunks][GS_REGION] u32
-    w.rows = w.vals + regions * (GS_REGION + 96) * 4;                                           // [L][nchunks][GS_REGION] u16
-    w.total = w.rows + regions * (GS_REGION + 96) * 2;
+    w.rows = w.vals + regions * GS_REGION * 4;                                                // [L][nchunks][GS_REGION] u16
+    w.total = w.rows + regions * GS_REGION * 2;
     return w;
 }
 
 __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
                                                  uint32_t* __restrict__ g_vals, uint16_t* __restrict__ g_rows, uint16_t* __restrict__ g_dir,
                                                  uint32_t B, uint32_t first, uint32_t count, uint32_t nchunks, ge_levels lv, uint32_t gridtype,
-                                                 bool align_corners, uint32_t stride) {
+                                                 bool align_corners) {
     __shared__ uint32_t s_vals[GS_REGION];             // 32 KiB: the region, slice-sorted
     __shared__ uint16_t s_rows[GS_REGION];             // 16 KiB
     __shared__ uint32_t s_hist[GS_MAX_SLICES + 1];     // entries per slice, then (after the scan) first entry of each slice
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
     }
     __syncthreads();
     const uint32_t total = s_hist[64];
-    const size_t region = ((size_t)level * nchunks + chunk) * stride;
+    const size_t region = ((size_t)level * nchunks + chunk) * GS_REGION;
     for (uint32_t k = tid; k < total; k += GS_CHUNK) g_vals[region + k] = s_vals[k];
     uint32_t* rows32 = reinterpret_cast<uint32_t*>(g_rows + region);
     const uint32_t* s_rows32 = reinterpret_cast<const uint32_t*>(s_rows);
@@ -870,8 +873,7 @@ __device__ __forceinline__ uint32_t gs_decode_wave(const int* __restrict__ offse
 template <typename OUT_T>
 __global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restrict__ g_vals, const uint16_t* __restrict__ g_rows,
                                                         const uint16_t* __restrict__ g_dir, const int* __restrict__ offsets, uint32_t* ticket,
-                                                        OUT_T* __restrict__ out, uint32_t L, uint32_t nchunks, float out_scale, bool add_to_out,
-                                                        uint32_t stride, int dbg) {
+                                                        OUT_T* __restrict__ out, uint32_t L, uint32_t nchunks, float out_scale, bool add_to_out) {
     extern __shared__ unsigned long long s_acc[];      // [GS_SLICE_ROWS][2] 64-bit fixed point (units of 2^-24)
     __shared__ uint32_t s_ticket, s_poison;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, sub = lane >> 4, l16 = lane & 15u;
@@ -906,16 +908,16 @@ __global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restri
             const uint32_t o = off, c = cnt, r = it * 4 + sub;
             off = 0; cnt = 0;
             if (it + 16 < n_it) { const uint32_t rn = (it + 16) * 4 + sub; if (rn < nchunks) { off = dir0[rn]; cnt = (uint32_t)dir1[rn] - off; } }
-            const size_t base = ((size_t)level * nchunks + r) * stride + o;
+            const size_t base = ((size_t)level * nchunks + r) * GS_REGION + o;
             for (uint32_t k = l16; k < c; k += 32) {
                 const bool two = k + 16 < c;
-                const uint32_t va = (dbg & 2) ? k : g_vals[base + k], ra = (dbg & 2) ? (k * 37u) & 4095u : g_rows[base + k];
+                const uint32_t va = g_vals[base + k], ra = g_rows[base + k];
                 const uint32_t vb = two ? g_vals[base + k + 16] : 0u, rb = two ? g_rows[base + k + 16] : 0xFFFFu;
                 long long q0, q1, q2, q3;
                 const bool fa = gs_half_to_fixed(va & 0xFFFFu, q0), fb = gs_half_to_fixed(va >> 16, q1);
                 const bool fc = gs_half_to_fixed(vb & 0xFFFFu, q2), fd = gs_half_to_fixed(vb >> 16, q3);
                 if (!(fa && fb && fc && fd)) s_poison = 1u;
-                else if (!(dbg & 1)) {
+                else {
                     if (ra < nrows) {
                         atomicAdd(&s_acc[2 * ra], (unsigned long long)q0);                  // ds_add_u64, no return
                         atomicAdd(&s_acc[2 * ra + 1], (unsigned long long)q1);
@@ -974,13 +976,13 @@ extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, co
         if (hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "grid_scatter_binned: memset failed");
         if (nchunks)
             hipLaunchKernelGGL(k_gs_bin, dim3(nchunks, L), dim3(GS_CHUNK), 0, s, (const _Float16*)grad, inputs, offsets, (uint32_t*)(base + w.vals),
-                               (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0, gs_stride());
+                               (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0);
         if (out_dtype == NGP_F32)
             hipLaunchKernelGGL(k_gs_accumulate<float>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
-                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (float*)grad_embeddings, L, nchunks, out_scale, add, gs_stride(), gs_debug_flags);
+                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (float*)grad_embeddings, L, nchunks, out_scale, add);
         else
             hipLaunchKernelGGL(k_gs_accumulate<_Float16>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
-                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (_Float16*)grad_embeddings, L, nchunks, out_scale, add, gs_stride(), gs_debug_flags);
+                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (_Float16*)grad_embeddings, L, nchunks, out_scale, add);
         first += count;
         add = true;
     } while (first < B);

@@ -98,15 +98,23 @@ class _field_train(Function):
         _hip.check(L.ngp_field_train_backward(ctypes.byref(ctx.fstruct), _hip.ptr(saved), _hip.ptr(d), M, _hip.ptr(g_sig), _hip.ptr(g_rgb),
                                               _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), _hip.stream()),
                    "field_train_backward")
+        # data-parallel training: the exchange (ngp/train.py GradExchange) takes the gradients as they appear -- the weight bucket now, so that its
+        # all-reduce runs underneath the table scatter; the table gradient as the half tensor the scatter writes, pre-divided by the world size
+        sink = getattr(field, "grad_sink", None)
+        if sink is not None:
+            inv = 1.0 / sink.world_size()
+            sink.deliver([field.sigma_net.weights, field.color_net.weights], torch.cat([g_ws, g_wc]).mul_(inv))
         grad_emb = None
         if ctx.needs_input_grad[2]:
             from gridencoder import grid as G
             inputs = ((x + field.bound) / (2 * field.bound)).contiguous()          # GridEncoder.forward (gridencoder/grid.py:144)
             S = float(np.log2(enc.per_level_scale))
             if G.BINNED_SCATTER and G.offsets_max_rows(enc.offsets) <= (1 << 19):
-                # summed on chip in float32 and written as the float32 gradient of the float32 parameter: no zero fill, no atomics, no widening
+                # summed on chip (exactly, 64-bit fixed point) and written once: as the float32 gradient of the float32 parameter (no zero fill, no
+                # atomics, no widening), or, for the exchange, as a half tensor scaled by 1 / world size (half the bytes on the links)
                 grad_emb = G.table_gradient_binned(grad_enc, inputs, enc.offsets, M, enc.num_levels, S, enc.base_resolution, enc.gridtype_id,
-                                                   enc.align_corners)
+                                                   enc.align_corners, out_dtype=torch.float16 if sink is not None else torch.float32,
+                                                   out_scale=(1.0 / sink.world_size()) if sink is not None else 1.0)
             else:
                 grad_emb = torch.zeros_like(emb_half)
                 dummy = torch.empty(1, dtype=torch.float16, device=x.device)
@@ -115,6 +123,12 @@ class _field_train(Function):
                                                           M, 3, enc.level_dim, enc.num_levels, S, enc.base_resolution, 0,
                                                           _hip.ptr(dummy), _hip.ptr(dummy), enc.gridtype_id, int(enc.align_corners), _hip.F16, _hip.stream()),
                                "grid_encode_backward")
+                if sink is not None:
+                    grad_emb.mul_(1.0 / sink.world_size())
+            if sink is not None:
+                sink.deliver(enc.embeddings, grad_emb)
+        if sink is not None:
+            return None, None, None, None, None, None
         return None, None, grad_emb, g_ws, g_wc, None
 
 
@@ -168,6 +182,7 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         self._fused = None
         self.fused_training = True           # training forwards under autocast go through _field_train when the field has the default shape
         self.fused_inference = True          # forwards without gradients under autocast go through forward_fused (one launch), likewise
+        self.grad_sink = None                # ngp/train.py GradExchange while a data-parallel step runs: the native backward delivers its gradients to it
         self._watch_parameters()
 
     def _fused_training_applies(self, x, d):

@@ -2,16 +2,27 @@
 
 Mirrors the optimisation recipe of main_nerf.py:124-135 / nerf/utils.py:774-794 -- Adam(betas 0.9/0.99, eps 1e-15),
 lr decayed by 0.1^(step/iters), fp16 autocast with a GradScaler, `update_extra_state` every 16 steps, MSE loss on
-4096-ray batches -- and adds what the reference never activated: data-parallel replicas that draw
-their own ray batches and exchange gradients with ONE all-reduce per step.
+4096-ray batches, an exponential moving average of the weights (decay 0.95) that evaluation renders with -- and adds what
+the reference never activated: data-parallel replicas that draw their own ray batches and exchange
+gradients once per step.
 
-Gradient exchange: the hash-table gradient (12.7 M float32 = 50.6 MB at bound 2) is dense and contiguous, so it is
-all-reduced in place -- no bucket copy; the MLP weights (< 80 KB) travel in one small flat bucket.  On 8 MI355X the
-xGMI links are point to point (7 x ~153 GB/s per GPU), so a ring moves 2*(7/8)*50.6 MB = 89 MB per GPU per step
-(~0.6 ms at one link pair); RCCL picks the algorithm, we only keep the payload in two messages.
-The GradScaler's overflow decision is made identical on every replica by reducing the found-inf flag with the gradients
-(a replica that skipped a step while the others did not would diverge).
+Gradient exchange (`GradExchange`).  Payload per step and rank: the hash-table gradient (12.7 M values) + the MLP weights
+(18 K values).  Two routes:
+  * the field's native training step (ngp/field.py `_field_train`) DELIVERS its gradients to the exchange while the backward
+    is still running: the MLP bucket (74 KB) as soon as the field's backward kernels are queued -- its all-reduce runs
+    underneath the table scatter --, and the table gradient as the HALF tensor the scatter writes, pre-divided by the world
+    size (25.3 MB instead of 50.6 MB of float32; the sum is then the mean and cannot overflow where a single rank's
+    gradient did not), all-reduced asynchronously right behind the scatter.  `finish()` waits and widens into `.grad`.
+    On 8 MI355X the xGMI links are point to point (7 x ~153 GB/s per GPU): a ring moves 2*(7/8)*25.3 MB = 44 MB per GPU per
+    step over one link pair (~0.3 ms), a direct reduce-scatter + all-gather 3.2 MB per link per phase; RCCL picks.
+  * anything else (the op-by-op graph, other fields, the CPU rehearsal) is reduced after the backward: large tensors in
+    place, the rest through one flat bucket.
+The GradScaler's overflow decision is identical on every replica by construction: the all-reduce sums the still-scaled
+gradients, so an inf or NaN on one rank is one on all ranks (a replica that skipped a step while the others did not would
+diverge).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -19,49 +30,172 @@ from . import sharding
 
 
 class GradExchange:
-    """Averages `.grad` of the given parameters across ranks: large tensors in place, the rest through one flat bucket."""
+    """Averages the gradients of `params` across ranks.  `deliver(param, grad)` starts the all-reduce of a gradient that a
+    native backward produced out of band (`grad` already divided by the world size, any float dtype); `__call__()` after the
+    backward reduces what autograd left in `.grad` and completes the delivered ones.  `stats` counts the bytes and (with
+    `timing=True`, CUDA only) the host-visible wait of the last step."""
 
-    def __init__(self, params, big_numel=1 << 20):
+    def __init__(self, params, big_numel=1 << 20, timing=False):
         self.params = [p for p in params if p.requires_grad]
         self.big = [p for p in self.params if p.numel() >= big_numel]
         self.small = [p for p in self.params if p.numel() < big_numel]
         self.bucket = None
+        self.pending = []                  # (param, delivered tensor, work handle)
+        self.timing = timing
+        self.stats = {"allreduce_bytes": 0, "exposed_ms": None}
+        self._events = None
 
+    # ---- out-of-band route -------------------------------------------------------------------------------------------
+    def active(self):
+        return sharding.collectives_on()
+
+    def world_size(self):
+        return sharding.world()[1]
+
+    def deliver(self, params, grad):
+        """grad: ONE contiguous tensor holding this rank's gradients of `params` (a parameter or a list of them, in order), ALREADY divided by
+        the world size, any float dtype; starts its SUM all-reduce and returns at once"""
+        params = [params] if isinstance(params, torch.Tensor) else list(params)
+        assert grad.numel() == sum(p.numel() for p in params)
+        work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True)
+        self.stats["allreduce_bytes"] += grad.numel() * grad.element_size()
+        self.pending.append((params, grad, work))
+
+    def _finish_pending(self):
+        delivered = set()
+        for params, grad, work in self.pending:
+            work.wait()                    # on the GPU: makes the current stream wait for the collective; the host does not block
+            flat, off = grad.reshape(-1), 0
+            for p in params:
+                g = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                g = g.to(p.dtype) if g.dtype != p.dtype else (g if len(params) == 1 else g.clone())
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.copy_(g)
+                delivered.add(id(p))
+        self.pending = []
+        return delivered
+
+    # ---- after the backward ------------------------------------------------------------------------------------------
     def __call__(self):
         rank, world = sharding.world()
         if not sharding.collectives_on():
+            self.pending = []
             return
+        if self.timing and torch.cuda.is_available():
+            self._events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._events[0].record()
+        done = self._finish_pending()
         inv = 1.0 / world
         for p in self.big:
+            if id(p) in done:
+                continue
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            self.stats["allreduce_bytes"] += p.grad.numel() * p.grad.element_size()
             p.grad.mul_(inv)
-        if self.small:
-            n = sum(p.numel() for p in self.small)
-            if self.bucket is None or self.bucket.numel() != n or self.bucket.device != self.small[0].device:
-                self.bucket = torch.empty(n, dtype=torch.float32, device=self.small[0].device)
+        small = [p for p in self.small if id(p) not in done]
+        if small:
+            n = sum(p.numel() for p in small)
+            if self.bucket is None or self.bucket.numel() != n or self.bucket.device != small[0].device:
+                self.bucket = torch.empty(n, dtype=torch.float32, device=small[0].device)
             off = 0
-            for p in self.small:
+            for p in small:
                 g = p.grad if p.grad is not None else torch.zeros_like(p)
                 self.bucket[off:off + p.numel()].copy_(g.reshape(-1))
                 off += p.numel()
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+            self.stats["allreduce_bytes"] += n * 4
             self.bucket.mul_(inv)
             off = 0
-            for p in self.small:
+            for p in small:
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
                 p.grad.copy_(self.bucket[off:off + p.numel()].view_as(p))
                 off += p.numel()
+        if self._events is not None:
+            self._events[1].record()
+
+    def begin_step(self):
+        self.stats["allreduce_bytes"] = 0
+
+    def exposed_ms(self):
+        """GPU time between the end of the backward and the last gradient being ready (events on the compute stream): what the step
+        waits for the collectives.  None when timing is off."""
+        if self._events is None:
+            return None
+        torch.cuda.synchronize()
+        return self._events[0].elapsed_time(self._events[1])
+
+
+class WeightEMA:
+    """Exponential moving average of the parameters, as the reference's Trainer keeps it (nerf/utils.py:324-325: torch_ema's
+    ExponentialMovingAverage(model.parameters(), decay=0.95); updated once per epoch :814-815 and per GUI burst :683-684; evaluation and the
+    "best" checkpoint render with the averaged weights :723-733, :851-853, :983-994).  torch_ema is a third-party package (environment.yml:24,
+    unpinned; absent from this image): its published algorithm (torch_ema 0.3, ema.py) is restated here --
+        update():  num_updates += 1;  d = min(decay, (1 + num_updates) / (10 + num_updates));  shadow -= (1 - d) * (shadow - param)
+        store() / copy_to() / restore():  park the live parameters, install the shadow ones, put the live ones back
+    -- parity unpinned by reference fixtures (the package cannot be imported here); tests/test_train_host.py checks the recurrence against
+    its closed form.  Replicas hold identical parameters, so their averages are identical without communication."""
+
+    def __init__(self, parameters, decay=0.95, use_num_updates=True):
+        self.params = [p for p in parameters if p.requires_grad]
+        self.decay = float(decay)
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow = [p.detach().clone() for p in self.params]
+        self.collected = None
+
+    @torch.no_grad()
+    def update(self):
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        one_minus = 1.0 - decay
+        tmp = torch._foreach_sub(self.shadow, [p.detach() for p in self.params])      # (shadow - param) * (1 - d), subtracted: torch_ema's order
+        torch._foreach_mul_(tmp, one_minus)
+        torch._foreach_sub_(self.shadow, tmp)
+
+    @torch.no_grad()
+    def store(self):
+        self.collected = [p.detach().clone() for p in self.params]
+
+    @torch.no_grad()
+    def copy_to(self):
+        for p, s in zip(self.params, self.shadow):
+            p.copy_(s)
+
+    @torch.no_grad()
+    def restore(self):
+        if self.collected is None:
+            raise RuntimeError("WeightEMA.restore() without a store()")
+        for p, c in zip(self.params, self.collected):
+            p.copy_(c)
+        self.collected = None
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow, "collected_params": self.collected}
+
+    def load_state_dict(self, state):
+        self.decay, self.num_updates = state["decay"], state["num_updates"]
+        with torch.no_grad():
+            for s, v in zip(self.shadow, state["shadow_params"]):
+                s.copy_(v)
 
 
 class NGPTrainer:
-    def __init__(self, renderer, lr=1e-2, iters=30000, fp16=True, update_extra_interval=16, seed=0, fused_adam=None):
+    def __init__(self, renderer, lr=1e-2, iters=30000, fp16=True, update_extra_interval=16, seed=0, fused_adam=None, ema_decay=0.95,
+                 steps_per_epoch=None, time_exchange=False):
+        """ema_decay: None disables the average (main_nerf.py:135 passes 0.95).  steps_per_epoch: the reference updates the average once per
+        epoch = once per pass over the training views (nerf/utils.py:814-815); with a number here `step()` calls `end_epoch()` itself."""
         self.ren = renderer
         self.fp16 = fp16
         self.iters = iters
         self.update_extra_interval = update_extra_interval
+        self.steps_per_epoch = steps_per_epoch
         # the device type comes from the model so that the 2-rank CPU rehearsal (tests/test_distributed_cpu.py, gloo) runs the very same step
         self.device_type = next(renderer.parameters()).device.type
         # Same update rule as the reference's Adam; on the GPU the fused implementation (one launch per parameter group instead of ~20
@@ -72,7 +206,8 @@ class NGPTrainer:
         self.opt = torch.optim.Adam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=bool(fused_adam))
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.scaler = torch.amp.GradScaler(self.device_type, enabled=fp16)
-        self.exchange = GradExchange(list(renderer.field.parameters()))
+        self.exchange = GradExchange(list(renderer.field.parameters()), timing=time_exchange)
+        self.ema = WeightEMA(renderer.field.parameters(), decay=ema_decay) if ema_decay is not None else None
         self.global_step = 0
         # the same pcg32 seed on every rank keeps the density grids of the replicas identical
         renderer.grid_seed = int(seed)
@@ -84,15 +219,49 @@ class NGPTrainer:
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 ren.update_extra_state()
         self.opt.zero_grad(set_to_none=True)
-        with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-            out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)
-            loss = torch.nn.functional.mse_loss(out["image"], target)
-        self.scaler.scale(loss).backward()
+        self.exchange.begin_step()
+        field = ren.field
+        if hasattr(field, "grad_sink"):
+            field.grad_sink = self.exchange if self.exchange.active() else None     # the native backward hands its gradients over as they appear
+        try:
+            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)
+                loss = torch.nn.functional.mse_loss(out["image"], target)
+            self.scaler.scale(loss).backward()
+        finally:
+            if hasattr(field, "grad_sink"):
+                field.grad_sink = None
         self.exchange()                              # gradients are still scaled; the scale is identical on every rank
         self.scaler.step(self.opt)
         self.scaler.update()
-        if hasattr(ren.field, "mark_updated"):
-            ren.field.mark_updated()                 # parameters changed (fused Adam does not say so through `_version`)
+        if hasattr(field, "mark_updated"):
+            field.mark_updated()                     # parameters changed (fused Adam does not say so through `_version`)
         self.sched.step()
         self.global_step += 1
+        if self.steps_per_epoch and self.global_step % self.steps_per_epoch == 0:
+            self.end_epoch()
         return loss.detach()
+
+    def end_epoch(self):
+        """nerf/utils.py:814-815: the moving average follows the weights once per epoch"""
+        if self.ema is not None:
+            self.ema.update()
+
+    @contextlib.contextmanager
+    def eval_weights(self):
+        """`with trainer.eval_weights(): renderer.render_fused(...)` renders with the averaged weights (nerf/utils.py:851-853, :933-934) and puts
+        the live ones back afterwards; without an average it is a no-op"""
+        field = self.ren.field
+        if self.ema is None:
+            yield
+            return
+        self.ema.store()
+        self.ema.copy_to()
+        if hasattr(field, "mark_updated"):
+            field.mark_updated()
+        try:
+            yield
+        finally:
+            self.ema.restore()
+            if hasattr(field, "mark_updated"):
+                field.mark_updated()

@@ -149,7 +149,7 @@ def _trainer_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ren = _MockRenderer(poison=7 if rank == 1 else None)
-        tr = NGPTrainer(ren, lr=1e-2, iters=100, fp16=True, update_extra_interval=4, seed=5)
+        tr = NGPTrainer(ren, lr=1e-2, iters=100, fp16=True, update_extra_interval=4, seed=5, ema_decay=0.95, steps_per_epoch=6)
         tr.exchange.big = [ren.field.table]                             # 8 K elements: force the in-place route for the table
         tr.exchange.small = [ren.field.w]
         g = torch.Generator().manual_seed(100 + rank)                   # every rank draws its OWN ray batch
@@ -163,8 +163,9 @@ def _trainer_worker(rank, world, port, out):
             skipped.append(bool(torch.equal(before, ren.field.w.detach())))
             scales.append(float(tr.scaler.get_scale()))
         # plain bytes through the queue: tensors would travel as shared-memory handles that die with this process
+        ema = b"".join(s.numpy().tobytes() for s in tr.ema.shadow) + bytes([tr.ema.num_updates])
         out.put((rank, ren.field.table.detach().numpy().tobytes(), ren.field.w.detach().numpy().tobytes(),
-                 ren.density_bitfield.numpy().tobytes(), scales, skipped, ren.iter_density, float(loss) == float(loss)))
+                 ren.density_bitfield.numpy().tobytes(), scales, skipped, ren.iter_density, ema))
     finally:
         dist.destroy_process_group()
 
@@ -184,10 +185,74 @@ def test_two_rank_trainer_replicas_stay_identical():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, t0, w0, b0, s0, k0, it0, _), (_, t1, w1, b1, s1, k1, it1, _) = res
+    (_, t0, w0, b0, s0, k0, it0, e0), (_, t1, w1, b1, s1, k1, it1, e1) = res
     assert t0 == t1 and w0 == w1 and b0 == b1 and it0 == it1 == 5
+    assert e0 == e1 and e0[-1] == 3                                      # the weight averages (3 epochs of 6 steps) are identical without communication
     assert s0 == s1 and k0 == k1
     assert k0[7] and not any(k0[:7]) and not any(k0[8:])                 # the poisoned step is skipped on both ranks, and only that one
     assert s0[7] == 0.5 * s0[6]
     fresh = _MockField()
     assert fresh.w.detach().numpy().tobytes() != w0                                # and training did move the parameters
+
+
+def _deliver_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import importlib
+    importlib.import_module("nerf-navigation_amd")
+    from ngp.train import GradExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(50 + rank)
+        table = torch.nn.Parameter(torch.zeros(6000, 2))
+        ws, wc = torch.nn.Parameter(torch.zeros(7168)), torch.nn.Parameter(torch.zeros(11264))
+        other = torch.nn.Parameter(torch.zeros(10))                        # a parameter autograd filled (the after-the-backward route)
+        # this rank's (loss-scaled) gradients: the table's as the native scatter writes it for the exchange = half, pre-divided by the world size
+        gt = torch.randn(6000, 2, generator=g) * 300.0
+        gt[::7] *= 1e-4                                                     # small entries next to large ones
+        gw = torch.randn(7168 + 11264, generator=g)
+        other.grad = torch.full((10,), float(rank + 1))
+        ex = GradExchange([table, ws, wc, other], big_numel=4096)
+        assert ex.active() and ex.world_size() == world
+        ex.begin_step()
+        ex.deliver([ws, wc], (gw / world).clone())
+        ex.deliver(table, (gt / world).to(torch.float16))
+        ex()
+        out.put((rank, gt.numpy().tobytes(), gw.numpy().tobytes(), table.grad.numpy().tobytes(), ws.grad.numpy().tobytes(), wc.grad.numpy().tobytes(),
+                 other.grad.numpy().tobytes(), str(table.grad.dtype), ex.stats["allreduce_bytes"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_delivered_half_table_gradient_equals_the_float32_exchange_to_half_precision():
+    """The overlapped exchange: the native backward delivers the weight bucket and the HALF table gradient, pre-divided by the
+    world size; the result is the float32 mean to within half-precision rounding (each rank's share and their sum are rounded to half: <= 1.5 half ulp),
+    identical on both ranks, widened to the parameter's dtype; a parameter that autograd filled still takes the after-the-backward route."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deliver_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = lambda b: np.frombuffer(b, np.float32)                              # noqa: E731
+    gt = [f(r[1]) for r in res]
+    gw = [f(r[2]) for r in res]
+    mean_t, mean_w = (gt[0].astype(np.float64) + gt[1]) / 2, (gw[0].astype(np.float64) + gw[1]) / 2
+    for r in res:
+        assert r[7] == "torch.float32"
+        assert r[3] == res[0][3] and r[4] == res[0][4] and r[5] == res[0][5]            # identical on both ranks
+        got = f(r[3]).astype(np.float64)
+        # three roundings to half (11 significant bits): each rank's share g_r / 2, then their sum -- half an ulp each, at the magnitude of the
+        # value that is rounded (the shares may be larger than their mean when they nearly cancel)
+        bound = 2.0 ** -11 * (np.abs(gt[0]) / 2 + np.abs(gt[1]) / 2 + np.abs(mean_t)) + 3 * 2.0 ** -25
+        assert np.all(np.abs(got - mean_t) <= 1.01 * bound)
+        assert np.abs(got - mean_t).max() > 0                                           # (it IS a half-precision exchange)
+        assert np.allclose(np.concatenate([f(r[4]), f(r[5])]), mean_w, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(f(r[6]), np.full(10, 1.5, np.float32))
+        assert r[8] == 6000 * 2 * 2 + (7168 + 11264) * 4 + 10 * 4                       # half table + float32 bucket + the small float32 bucket

@@ -62,11 +62,11 @@ def test_binned_scatter_against_oracle_and_atomic_kernel(oracle, dev, case, out_
 
 
 def test_binned_scatter_multi_pass_and_empty(oracle, dev):
-    """more than 2^21 samples run in passes that add into the output; B = 0 writes zeros"""
+    """more than 2^22 samples run in passes that add into the output; B = 0 writes zeros"""
     from gridencoder import grid as G
     L = 4
     offsets, pls = oracle.grid_offsets(3, L, 2, 2, 16, 12, 64, False)
-    B = (1 << 21) + 12345
+    B = (1 << 22) + 12345
     x = ray_points(B // 64 + 1, 64, 5)[:B]
     grad = np.full((L, B, 2), 0.001, np.float16)
     out = G.table_gradient_binned(t(grad, dev), t(x, dev), t(offsets, dev), B, L, np.log2(pls), 16, 0, False)

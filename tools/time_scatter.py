@@ -22,7 +22,6 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--sparse", action="store_true")
 ap.add_argument("--only", default="both", choices=["both", "atomic", "binned"])
-ap.add_argument("--debug", type=int, default=0, help="ngp_grid_scatter_debug flags (timing experiments)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(200, 200), 200, 200)
@@ -44,8 +43,6 @@ L = enc.num_levels
 grad = (torch.randn(L, M, 2, device=dev) * 1e-2).half()
 S = float(np.log2(enc.per_level_scale))
 lib = hip.lib()
-if args.debug:
-    lib.raw.ngp_grid_scatter_debug(args.debug)
 dummy = torch.empty(1, dtype=torch.float16, device=dev)
 
 
