@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--no-fit", action="store_true", help="skip the `fitted` block (the same frame kernel timed on a model fitted for --fit-steps steps, SURVEY 8d cfg 2)")
     ap.add_argument("--fit-frames", type=int, default=30, help="timed 800x800 frames of the fitted model (after 5 warm-up frames)")
     ap.add_argument("--fit-cpu-res", type=int, default=200, help="side of the view on which the fitted student is rendered by the CPU oracle too (psnr_delta_db); <= 200")
+    ap.add_argument("--frames-per-launch", type=int, default=8, help="secondary `multi_frame` block: this many poses rendered by ONE launch (1 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="N = 1: initialise the nccl (= RCCL) process group anyway and take every collective of the N > 1 path")
     ap.add_argument("--path", default="fused", choices=["fused", "fused_camera", "fused_torch_rays", "drop_in", "per_op", "per_op_fused_field"],
                     help="fused = headline (rays resident); fused_camera = rays generated inside the frame kernel from the pose; "
@@ -514,6 +515,32 @@ def main():
         else:
             result["roofline"]["traffic_stale"] = info
 
+    if args.path == "fused" and world == 1 and not strong and args.frames_per_launch > 1 and H % 8 == 0 and Wd % 8 == 0:
+        # secondary: P poses per launch (ngp_render_frames_camera): the same pixels; ramp and drain of the persistent kernel paid once per P frames.
+        # The headline `value` stays one frame per launch (BASELINE's metric: a viewer renders the frame it needs now).
+        P_ = args.frames_per_launch
+        poses_np = np.stack([poses[k % n_poses] for k in range(P_)])
+        for _ in range(2):
+            ren.render_fused_cameras(poses_np, intr, H, Wd, dt_gamma=0, bg_color=1, max_steps=1024)
+        torch.cuda.synchronize()
+        n_launch = max(args.steps // P_, 3)
+        evm, stm = [], []
+        t1 = time.perf_counter()
+        for _ in range(n_launch):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            outm = ren.render_fused_cameras(poses_np, intr, H, Wd, dt_gamma=0, bg_color=1, max_steps=1024)
+            b.record()
+            evm.append((a, b)); stm.append(outm["stats"])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        smp = int(torch.stack(stm)[:, 0].to(torch.int64).sum().item())
+        k_s = 1e-3 * float(np.mean([a.elapsed_time(b) for a, b in evm]))
+        ach = GATHER_BYTES_PER_SAMPLE * (smp / n_launch) / k_s / 1e9
+        result["multi_frame"] = {"frames_per_launch": P_, "launches": n_launch, "value": smp / el, "unit": "ray-samples/s", "ms_per_frame": 1e3 * el / (n_launch * P_),
+                                 "fps": n_launch * P_ / el, "rays": "generated in the kernel from the poses (camera mode)",
+                                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                              "kernel": "k_render_frame_multi", "avg_launch_ms": 1e3 * k_s}}
     if fit is not None:
         result["fit"] = fit
     if args.model == "handset" and args.path == "fused" and world == 1 and not strong and not args.no_fit:

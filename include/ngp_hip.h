@@ -396,6 +396,17 @@ int ngp_render_frame_camera(const ngp_field_t* field_host, const float* pose_hos
                             float* image, float* depth, float* weights_sum, uint32_t* stats,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* P frames of one camera model in ONE launch (poses_host [P][16] row-major 4x4 cam2world on the host; outputs [P][H*W] contiguous): the
+ * frame kernel's ramp and drain are paid once per launch instead of once per frame.  The same pixels, bit for bit, as P calls of
+ * ngp_render_frame_camera.  H, W multiples of 8; 1 <= P <= 64; workspace: ngp_render_frames_workspace(P, H * W) bytes.
+ * (No reference counterpart: nerf/utils.py:588-638 renders a test set one frame per call.) */
+size_t ngp_render_frames_workspace(uint32_t P, uint32_t rays_per_frame);
+int ngp_render_frames_camera(const ngp_field_t* field, const float* poses_host, uint32_t P, const float* intrinsics_host, uint32_t H, uint32_t W,
+                             const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                             float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                             float* image, float* depth, float* weights_sum, uint32_t* stats,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

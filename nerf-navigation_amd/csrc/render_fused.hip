@@ -133,6 +133,8 @@ static constexpr uint32_t RV_LDS_LV = 4 * 96;                          // rf_lan
 struct rf_frame {
     const float* rays_o; const float* rays_d; uint32_t N;   // rays_o == null: the rays are those of `cam` (pixel = ray id)
     ngp_camera cam;
+    const ngp_camera* cams; uint32_t frame_rays;             // several frames in one launch (ngp_render_frames_camera): ray r belongs to pixel
+                                                             // r % frame_rays of camera cams[r / frame_rays]; null = one frame, `cam`
     float aabb[6]; float min_near;
     const uint8_t* bitfield; uint32_t C, H;
     float dt_gamma; uint32_t max_steps;
@@ -667,6 +669,11 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                         if (F.rays_o) {
                             #pragma unroll
                             for (int k = 0; k < 3; k++) { o[k] = F.rays_o[3ull * ray + k]; d[k] = F.rays_d[3ull * ray + k]; }
+                        } else if (F.cams) {               // camera mode, several frames per launch: the frame's camera from memory (a tile lies in one frame)
+                            const uint32_t f = ray / F.frame_rays;
+                            const ngp_camera c = F.cams[f];
+                            o[0] = c.t[0]; o[1] = c.t[1]; o[2] = c.t[2];
+                            ngp_camera_ray(c, ray - f * F.frame_rays, d);
                         } else {                           // camera mode: get_rays fused into the refill (nerf/utils.py:98-108)
                             o[0] = F.cam.t[0]; o[1] = F.cam.t[1]; o[2] = F.cam.t[2];
                             ngp_camera_ray(F.cam, ray, d);
@@ -1062,7 +1069,7 @@ static int rv_fill_camera(const char* who, const float* pose_host, const float* 
     return NGP_OK;
 }
 
-static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, const ngp_camera* cam, uint32_t N,
+static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, const ngp_camera* cam, uint32_t n_cams, uint32_t N,
                            uint32_t image_width, const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
                            float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
                            float* image, float* depth, float* weights_sum, uint32_t* stats,
@@ -1081,6 +1088,15 @@ static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, c
     rf_frame F;
     F.rays_o = cam ? nullptr : rays_o; F.rays_d = cam ? nullptr : rays_d; F.N = N;
     F.cam = cam ? *cam : ngp_camera{};
+    F.cams = nullptr; F.frame_rays = N;
+    if (cam && n_cams > 1) {
+        // the cameras travel in the workspace, behind the coarse occupancy map and the tile area (pageable host memory: the copy is staged before the call returns)
+        const size_t at = (ngp_render_frame_workspace(N) + 255) & ~(size_t)255;
+        NGP_REQUIRE(workspace_bytes >= at + n_cams * sizeof(ngp_camera), "render_frames_camera: workspace too small (ngp_render_frames_workspace)");
+        ngp_camera* dst = reinterpret_cast<ngp_camera*>(reinterpret_cast<unsigned char*>(workspace) + at);
+        if (hipMemcpyAsync(dst, cam, n_cams * sizeof(ngp_camera), hipMemcpyHostToDevice, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "render_frames_camera: camera copy failed");
+        F.cams = dst; F.frame_rays = N / n_cams;
+    }
     for (int i = 0; i < 6; i++) F.aabb[i] = aabb_host[i];
     F.min_near = min_near; F.bitfield = bitfield; F.C = C; F.H = Hgrid;
     F.dt_gamma = dt_gamma; F.max_steps = max_steps;
@@ -1168,7 +1184,7 @@ extern "C" int ngp_render_frame(const ngp_field_t* field_host, const float* rays
                                 float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
                                 float* image, float* depth, float* weights_sum, uint32_t* stats,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-    return rv_render_frame(field_host, rays_o, rays_d, nullptr, N, image_width, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
+    return rv_render_frame(field_host, rays_o, rays_d, nullptr, 0, N, image_width, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
                            bg_color3_host, image, depth, weights_sum, stats, workspace, workspace_bytes, stream);
 }
 
@@ -1182,7 +1198,33 @@ extern "C" int ngp_render_frame_camera(const ngp_field_t* field_host, const floa
     ngp_camera cam;
     const int rc = rv_fill_camera("render_frame_camera", pose_host, intrinsics_host, H, W, cam);
     if (rc != NGP_OK) return rc;
-    return rv_render_frame(field_host, nullptr, nullptr, &cam, H * W, W, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
+    return rv_render_frame(field_host, nullptr, nullptr, &cam, 1, H * W, W, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
+                           bg_color3_host, image, depth, weights_sum, stats, workspace, workspace_bytes, stream);
+}
+
+// P frames in ONE launch: poses_host [P][16] (row-major 4x4, cam2world), one set of intrinsics; outputs [P][H*W] contiguous.  The frame kernel's
+// ramp (256 workgroups staging 36 KiB of weights, the first tiles marching) and drain (the last waves finishing alone) are paid once per
+// launch instead of once per frame: the same pixels, bit for bit, as P calls of ngp_render_frame_camera.  H and W must be multiples of 8
+// (an 8x8 tile then never straddles two frames).  Workspace: ngp_render_frames_workspace(P, H * W).
+extern "C" size_t ngp_render_frames_workspace(uint32_t P, uint32_t rays_per_frame) {
+    return ((ngp_render_frame_workspace(P * rays_per_frame) + 255) & ~(size_t)255) + (size_t)P * sizeof(ngp_camera);
+}
+
+extern "C" int ngp_render_frames_camera(const ngp_field_t* field_host, const float* poses_host, uint32_t P, const float* intrinsics_host, uint32_t H, uint32_t W,
+                                        const float* aabb_host, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
+                                        float dt_gamma, uint32_t max_steps, const float* bg_color3_host,
+                                        float* image, float* depth, float* weights_sum, uint32_t* stats,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(P >= 1 && P <= 64, "render_frames_camera: 1..64 frames per launch");
+    NGP_REQUIRE(H % 8 == 0 && W % 8 == 0, "render_frames_camera: H and W must be multiples of 8");
+    NGP_REQUIRE((uint64_t)P * H * W <= 0xFFFFFFFFull, "render_frames_camera: too many rays");
+    NGP_REQUIRE(poses_host, "render_frames_camera: poses is a host pointer and must not be null");
+    ngp_camera cams[64];
+    for (uint32_t p = 0; p < P; p++) {
+        const int rc = rv_fill_camera("render_frames_camera", poses_host + 16 * p, intrinsics_host, H, W, cams[p]);
+        if (rc != NGP_OK) return rc;
+    }
+    return rv_render_frame(field_host, nullptr, nullptr, cams, P, P * H * W, W, aabb_host, min_near, bitfield, C, Hgrid, dt_gamma, max_steps,
                            bg_color3_host, image, depth, weights_sum, stats, workspace, workspace_bytes, stream);
 }
 

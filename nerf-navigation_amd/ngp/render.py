@@ -234,6 +234,34 @@ class NGPRenderer(nn.Module):
                                              _hip.ptr(ws), ws.numel(), _hip.stream()), "render_frame_camera")
         return {"image": image.view(H, W, 3), "depth": depth.view(H, W), "weights_sum": weights_sum, "stats": stats}
 
+    @torch.no_grad()
+    def render_fused_cameras(self, poses, intrinsics, H, W, dt_gamma=0, bg_color=None, max_steps=1024):
+        """P frames in ONE launch (ngp_render_frames_camera): poses [P,4,4] cam2world (tensor, array or nested lists), one set of intrinsics.
+        The frame kernel's ramp and drain are paid once per launch instead of once per frame; every pixel equals `render_fused_camera`'s, bit
+        for bit.  Returns image [P,H,W,3], depth [P,H,W], weights_sum [P,H*W], stats (summed over the frames)."""
+        device = self.density_bitfield.device
+        if isinstance(poses, torch.Tensor):
+            poses = poses.detach().cpu().numpy()
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4))
+        P, N = poses.shape[0], int(H) * int(W)
+        image = torch.empty(P * N, 3, dtype=torch.float32, device=device)
+        depth = torch.empty(P * N, dtype=torch.float32, device=device)
+        weights_sum = torch.empty(P * N, dtype=torch.float32, device=device)
+        stats = torch.empty(4, dtype=torch.int32, device=device)
+        if bg_color is None:
+            bg_color = 1
+        bg = (ctypes.c_float * 3)(*([float(bg_color)] * 3 if np.isscalar(bg_color) else [float(v) for v in bg_color]))
+        aabb = (ctypes.c_float * 6)(*[float(v) for v in self._aabb().tolist()])
+        intr = (ctypes.c_float * 4)(*[float(v) for v in intrinsics])
+        L = _hip.lib()
+        ws = _hip.workspace(L.ngp_render_frames_workspace(P, N), device)
+        f = self.field.fused_state(self.density_scale)
+        _hip.check(L.ngp_render_frames_camera(ctypes.byref(f), poses.ctypes.data_as(ctypes.c_void_p), P, intr, int(H), int(W), aabb, self.min_near,
+                                              _hip.ptr(self.density_bitfield), self.cascade, self.grid_size, dt_gamma, max_steps, bg,
+                                              _hip.ptr(image), _hip.ptr(depth), _hip.ptr(weights_sum), _hip.ptr(stats),
+                                              _hip.ptr(ws), ws.numel(), _hip.stream()), "render_frames_camera")
+        return {"image": image.view(P, H, W, 3), "depth": depth.view(P, H, W), "weights_sum": weights_sum.view(P, N), "stats": stats}
+
     # ------------------------------------------------------------------------------------------------------------
     # fixed-step path (nav loop)
     # ------------------------------------------------------------------------------------------------------------

@@ -88,6 +88,9 @@ _SIGNATURES = {
     "ngp_get_rays": (c_int, [c_vp, c_vp, c_u32, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_render_frame_camera": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_render_frames_workspace": (c_sz, [c_u32, c_u32]),
+    "ngp_render_frames_camera": (c_int, [c_vp, c_vp, c_u32, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
+                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -80,3 +80,31 @@ def test_frame_from_camera_equals_frame_from_rays(dev, H, W):
     ref = R.render_single_march(lambda x, dd: R.field_forward(model, x, dd, 1.0), ro, rd, bf, Wk.BOUND, 2, bg_color=np.array(bg, np.float32))
     assert np.max(np.abs(a["image"].reshape(-1, 3).cpu().numpy() - ref["image"])) < 5e-3
     assert abs(int(a["stats"][0]) - ref["samples"]) <= max(8, 3e-4 * ref["samples"])
+
+
+def test_frames_in_one_launch_equal_single_frame_launches(dev):
+    """ngp_render_frames_camera: P frames per launch (ramp and drain of the frame kernel paid once): every pixel, depth, weights_sum and the
+    summed statistics equal those of P single-frame camera launches, bit for bit; H, W must be multiples of 8; 1..64 frames."""
+    from ngp import workload as Wk
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    field = NGPFieldFF(bound=Wk.BOUND).to(dev).load_arrays(Wk.make_model(0))
+    ren = NGPRenderer(field, bound=Wk.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
+    ren.load_density_grid(Wk.density_grid())
+    H, W = 48, 64
+    intr = Wk.intrinsics(H, W)
+    poses = np.stack([Wk.orbit_pose(k, 5) for k in range(5)])
+    bg = (0.2, 0.4, 0.9)
+    many = ren.render_fused_cameras(poses, intr, H, W, bg_color=bg)
+    assert many["image"].shape == (5, H, W, 3)
+    total = torch.zeros(3, dtype=torch.int64, device=dev)
+    for k in range(5):
+        one = ren.render_fused_camera(poses[k], intr, H, W, bg_color=bg)
+        assert torch.equal(many["image"][k], one["image"])
+        assert torch.equal(many["depth"][k].nan_to_num(), one["depth"].nan_to_num())
+        assert torch.equal(many["weights_sum"][k], one["weights_sum"])
+        total += one["stats"][:3].to(torch.int64)
+    assert torch.equal(many["stats"][:3].to(torch.int64), total) and int(total[0]) > 10000
+    assert torch.equal(ren.render_fused_cameras(poses[:1], intr, H, W, bg_color=bg)["image"][0], many["image"][0])
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ren.render_fused_cameras(poses, Wk.intrinsics(30, 50), 30, 50)
