@@ -98,6 +98,9 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
                                // 0 (off): 3.49 | 5.3, 5.3    8: 3.53 | 8.1, 6.7    12: 3.51 | 7.8    16: 3.46 | 8.1, 6.9    24: 3.45 | 7.7, 6.6    32: 3.46 | 7.3, 6.5    48: 3.49 | 6.7
                                // (limiting every lane to (smallest t of the wave) + 24 steps instead -- the laggard crawls through its empty space 24 steps a
                                //  round -- gave 7.4-7.7 on the fitted model but 4.06 ms on the hand-set one: rounds of 87 samples instead of 636)
+#ifndef RV_CU_CHUNKS
+#define RV_CU_CHUNKS 0         // 1: the waves of a workgroup (= one CU) draw their 8x8 tiles from a CU-LOCAL chunk of 8 tiles = a block of 4 x 2 adjacent tiles
+#endif                         // (32 x 16 pixels), fetched from the band queue with one atomic: neighbouring tiles share an L1.  A/B on MI355X: see DESIGN 3.2.
 #ifndef RV_BLOCK_THREADS
 #define RV_BLOCK_THREADS 512
 #endif
@@ -129,6 +132,7 @@ static constexpr int RV_WAVES = RV_BLOCK / 64;
 static constexpr uint32_t RV_LDS_W = RV_NFRAG * 1024;                  // weight fragments
 static constexpr uint32_t RV_LDS_SH = RV_WAVES * 64 * 32;              // 16 halves per lane
 static constexpr uint32_t RV_LDS_LV = 4 * 96;                          // rf_lane_levels of the 4 lane groups
+static constexpr uint32_t RV_LDS_CHUNK = RV_CU_CHUNKS ? 16 : 0;        // the CU's current tile chunk (one 64-bit word), k_render_frame_multi only
 
 struct rf_frame {
     const float* rays_o; const float* rays_d; uint32_t N;   // rays_o == null: the rays are those of `cam` (pixel = ray id)
@@ -324,12 +328,22 @@ __global__ __launch_bounds__(RF_BLOCK, RF_FIELD_WG_PER_CU) void k_field_forward_
 // queue index -> ray id.  With tile_w set (rays are a row-major image whose width and height are multiples of 8)
 // consecutive queue indices walk 8x8 pixel tiles, so the 64 lanes of a wave start on a compact patch of the image
 // and their gathers share cache lines; otherwise the identity.
-__device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w, const uint32_t* __restrict__ tile_order) {
+__device__ __forceinline__ uint32_t rv_ray_of(uint32_t idx, uint32_t tile_w, const uint32_t* __restrict__ tile_order, uint32_t n_rays = 0) {
     if (tile_w == 0) return idx;
     uint32_t tile = idx >> 6;
     const uint32_t in = idx & 63u, tiles_x = tile_w >> 3;
     if (tile_order) tile = tile_order[tile];
+#if RV_CU_CHUNKS
+    // eight consecutive tiles form a block of 4 x 2 tiles (the chunk a CU draws at once) when the image divides into such blocks (else row-major as before)
+    uint32_t ty, tx;
+    if ((tiles_x & 3u) == 0 && ((n_rays / tile_w) & 15u) == 0) {      // whole 4 x 2 blocks only: the image is a multiple of 32 x 16 pixels
+        const uint32_t c = tile >> 3, i = tile & 7u, bpr = tiles_x >> 2;
+        const uint32_t by = c / bpr, bx = c - by * bpr;
+        ty = by * 2 + (i >> 2); tx = bx * 4 + (i & 3u);
+    } else { ty = tile / tiles_x; tx = tile - ty * tiles_x; }
+#else
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+#endif
 #if RV_PATCH_4X4
     // lanes 16p..16p+15 (one MFMA column tile, one gather instruction group) cover a compact 4x4 pixel patch
     const uint32_t p = in >> 4, s = in & 15u;
@@ -588,7 +602,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
 template <bool FIXED>
 __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame& F, const rf_iter_class cls_rt,
                                               const ngp_h8* __restrict__ lds_w, _Float16* lds_sh, const rf_lane_levels* lds_lv,
-                                              float4* lds_smp, const uint32_t* lds_coarse) {
+                                              float4* lds_smp, const uint32_t* lds_coarse, unsigned long long* lds_chunk) {
     const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the same, known to be uniform
@@ -617,6 +631,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
 #if RV_XCD_QUEUES
     uint32_t rv_q = blockIdx.x & 7u, rv_q_seen = 0;        // blockIdx % 8 labels the workgroups that share an XCD
 #endif
+    (void)lds_chunk;
     rv_block_cache bc;                                 // bitfield word of the block the ray last tested (block ids are global: stays valid across rays)
     uint32_t n_samples_local = 0, n_tiles = 0, n_capped_local = 0, n_hit_local = 0;
 #ifdef RV_COUNTERS
@@ -643,7 +658,53 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             if (need && (uint32_t)__popcll(need) >= RV_REFILL_MIN) {
                 const uint32_t cnt = (uint32_t)__popcll(need);
                 uint32_t base = 0;
-#if RV_XCD_QUEUES
+#if RV_XCD_QUEUES && RV_CU_CHUNKS && RV_REFILL_MIN == 64
+                // One 8x8 tile for this wave, out of the CU's current chunk of 8 adjacent tiles (LDS word, compare-and-swap); the wave that finds the chunk
+                // used up fetches the next one from ITS band's queue with one atomic and publishes it while the others wait.  Bands start at multiples of 8 tiles.
+                const uint32_t n_tiles64 = (F.N + 63u) >> 6;
+                uint32_t q_hi = 0;
+                {
+                    uint32_t tile = 0xFFFFFFFFu, band = rv_q;
+                    if (lane == 0) {
+                        for (;;) {
+                            const unsigned long long d = __hip_atomic_load(lds_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const uint32_t taken = (uint32_t)(d >> 32) & 0xFFu;
+                            unsigned long long want = d;
+                            if (taken < 8u) {                  // a tile is left: take it
+                                if (__hip_atomic_compare_exchange_strong(lds_chunk, &want, d + (1ull << 32), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                    tile = (uint32_t)d + taken; band = (uint32_t)(d >> 40); break;
+                                }
+                            } else if (taken == 8u) {          // used up: ONE wave fetches the next chunk (state 0xFF while it does), the others wait for it
+                                if (__hip_atomic_compare_exchange_strong(lds_chunk, &want, d | (0xFFull << 32), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                    const uint32_t b_lo = (uint32_t)(((unsigned long long)n_tiles64 * rv_q) / RV_BANDS) & ~7u;
+                                    const uint32_t b_hi = rv_q + 1u == RV_BANDS ? n_tiles64 : ((uint32_t)(((unsigned long long)n_tiles64 * (rv_q + 1u)) / RV_BANDS) & ~7u);
+                                    const uint32_t got = atomicAdd(F.queue + 32 + rv_q, 8u) + b_lo;
+                                    if (got >= b_hi) {         // this wave's band is dry: hand the slot back, move on to the next band
+                                        __hip_atomic_store(lds_chunk, 8ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        tile = 0xFFFFFFFEu; break;
+                                    }
+                                    __hip_atomic_store(lds_chunk, (unsigned long long)got | ((unsigned long long)rv_q << 40) | (1ull << 32), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    tile = got; break;
+                                }
+                            } else {
+                                __builtin_amdgcn_s_sleep(4);   // a fetch is in flight (one global atomic: ~2 us)
+                            }
+                        }
+                    }
+                    tile = __shfl(tile, 0, 64); band = __shfl(band, 0, 64);
+                    if (tile == 0xFFFFFFFEu) {             // band dry: move on (same walk as the plain queues), try again next round
+                        rv_q += 8u;
+                        if (rv_q >= RV_BANDS) rv_q = (rv_q + 1u) & 7u;
+                        if (++rv_q_seen == RV_BANDS) exhausted = true;
+                        continue;
+                    }
+                    const uint32_t t_hi = band + 1u == RV_BANDS ? n_tiles64 : ((uint32_t)(((unsigned long long)n_tiles64 * (band + 1u)) / RV_BANDS) & ~7u);
+                    base = tile << 6;
+                    q_hi = tile < t_hi ? ((tile + 1u) << 6) : 0u;                                // a chunk may reach past its band's end: those tiles are nobody's
+                    q_hi = q_hi < F.N ? q_hi : F.N;
+                }
+#elif RV_XCD_QUEUES
                 // Queue q holds the rays of image band q (tiles [T q / RV_BANDS, T (q + 1) / RV_BANDS) of 64 rays): the workgroups of one XCD
                 // work on the same band, so that the table lines neighbouring rays share are fetched into ONE L2 and
                 // not into eight.  A wave that finds its queue empty moves on to its XCD's next band, then to the other XCDs'.
@@ -664,7 +725,7 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
 #else
                     if (idx < F.N) {
 #endif
-                        ray = rv_ray_of(idx, F.tile_w, F.tile_order);
+                        ray = rv_ray_of(idx, F.tile_w, F.tile_order, F.N);
                         float o[3], d[3];
                         if (F.rays_o) {
                             #pragma unroll
@@ -691,7 +752,9 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                         active = true;
                     }
                 }
-#if RV_XCD_QUEUES
+#if RV_XCD_QUEUES && RV_CU_CHUNKS && RV_REFILL_MIN == 64
+                (void)cnt;
+#elif RV_XCD_QUEUES
                 if (base + cnt >= q_hi) {                  // this queue has run dry: move on, until all eight have been seen
                     // XCD x owns bands x, x + 8, x + 16, ...: thin bands spread over the whole image, so that every XCD gets a fair sample of cheap and
                     // expensive rows; when its own are done it goes on with the next XCD's
@@ -1019,10 +1082,14 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rv_smem);
     _Float16* lds_sh = reinterpret_cast<_Float16*>(rv_smem + RV_LDS_W);
     rf_lane_levels* lds_lv = reinterpret_cast<rf_lane_levels*>(rv_smem + RV_LDS_W + RV_LDS_SH);
-    float4* lds_smp = reinterpret_cast<float4*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV);
-    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_SMP) : nullptr;
+    float4* lds_smp = reinterpret_cast<float4*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_CHUNK);
+    uint32_t* lds_coarse = F.coarse ? reinterpret_cast<uint32_t*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV + RV_LDS_CHUNK + RV_LDS_SMP) : nullptr;
+    unsigned long long* rv_chunk_p = reinterpret_cast<unsigned long long*>(rv_smem + RV_LDS_W + RV_LDS_SH + RV_LDS_LV);   // (RV_CU_CHUNKS only)
 
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
+#if RV_CU_CHUNKS
+    if (threadIdx.x == 0) *rv_chunk_p = 8ull << 32;    // {first tile of the CU's current chunk : 32 | tiles taken : 8 | band : 24}; "all 8 taken": the first wave to ask fetches one
+#endif
 
     rv_stage_weights(P, lds_w, wave, RV_WAVES, lane);
     if (lds_coarse) {
@@ -1037,9 +1104,9 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     __syncthreads();
     const rf_iter_class cls = rf_classify(lds_lv[g]);
     if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u)
-        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse);
+        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse, rv_chunk_p);
     else
-        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse);
+        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse, rv_chunk_p);
 }
 #endif  // RV_S > 1
 
@@ -1121,7 +1188,7 @@ static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, c
     static_assert(sizeof(rf_lane_levels) * 4 == RV_LDS_LV, "LDS carve of the level table");
     size_t lds = RV_LDS_W + RV_LDS_SH + RV_LDS_LV;
 #if RV_S > 1
-    lds += RV_LDS_SMP;
+    lds += RV_LDS_SMP + RV_LDS_CHUNK;
     const void* kernel = reinterpret_cast<const void*>(k_render_frame_multi);
 #else
     const void* kernel = reinterpret_cast<const void*>(k_render_frame);

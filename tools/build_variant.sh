@@ -1,9 +1,9 @@
 # Build a variant of libngp_hip.so with extra -D flags for render_fused.hip: bash tools/build_variant.sh <name> [-DFOO=1 ...]
-# -> nerf-navigation_amd/lib/var/libngp_<name>.so (select it with NGP_HIP_LIB=...; tools/ab_variants.sh times several)
+# -> build/var/libngp_<name>.so (select it with NGP_HIP_LIB=...; tools/ab_variants.sh times several)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
-V=$ROOT/nerf-navigation_amd/lib/var
+V=$ROOT/build/var
 mkdir -p $V
 cd $ROOT/nerf-navigation_amd/csrc
 make -s >/dev/null

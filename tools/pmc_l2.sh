@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
 for V in "$@"; do
-  export NGP_HIP_LIB=$R/nerf-navigation_amd/lib/var/libngp_$V.so
-  timeout -k 10 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $R/gpurun_out/l2_${V} -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu > $R/gpurun_out/l2_${V}.log 2>&1
+  export NGP_HIP_LIB=$R/build/var/libngp_$V.so
+  timeout -k 10 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $R/gpurun_out/l2_${V} -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --frames-per-launch 1 > $R/gpurun_out/l2_${V}.log 2>&1
   python3 - <<PY
 import csv, glob, os, collections
 fs = sorted(glob.glob("$R/gpurun_out/l2_${V}/*/*counter_collection.csv"), key=os.path.getmtime)
