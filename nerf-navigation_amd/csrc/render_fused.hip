@@ -132,7 +132,7 @@ static constexpr int RV_WAVES = RV_BLOCK / 64;
 static constexpr uint32_t RV_LDS_W = RV_NFRAG * 1024;                  // weight fragments
 static constexpr uint32_t RV_LDS_SH = RV_WAVES * 64 * 32;              // 16 halves per lane
 static constexpr uint32_t RV_LDS_LV = 4 * 96;                          // rf_lane_levels of the 4 lane groups
-static constexpr uint32_t RV_LDS_CHUNK = RV_CU_CHUNKS ? 16 : 0;        // the CU's current tile chunk (one 64-bit word), k_render_frame_multi only
+[[maybe_unused]] static constexpr uint32_t RV_LDS_CHUNK = RV_CU_CHUNKS ? 16 : 0;        // the CU's current tile chunk (one 64-bit word), k_render_frame_multi only
 
 struct rf_frame {
     const float* rays_o; const float* rays_d; uint32_t N;   // rays_o == null: the rays are those of `cam` (pixel = ray id)

@@ -13,8 +13,8 @@ FLAGS = ["--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("defs", [["-DRV_S=1"], ["-DRV_PIPELINE=1", "-DRV_TILE_ORDER=1", "-DRV_COUNTERS=1", "-DRV_BLOCK_SKIP=0"]],
-                         ids=["single_sample_kernel", "pipeline_tileorder_counters"])
+@pytest.mark.parametrize("defs", [["-DRV_S=1"], ["-DRV_PIPELINE=1", "-DRV_TILE_ORDER=1", "-DRV_COUNTERS=1", "-DRV_BLOCK_SKIP=0"], ["-DRV_CU_CHUNKS=1"]],
+                         ids=["single_sample_kernel", "pipeline_tileorder_counters", "cu_local_tile_chunks"])
 def test_render_fused_option_builds(tmp_path, defs):
     src = os.path.join(ROOT, "nerf-navigation_amd", "csrc", "render_fused.hip")
     out = subprocess.run([HIPCC] + FLAGS + defs + [src, "-o", str(tmp_path / "rf.o")], capture_output=True, text=True, timeout=600)

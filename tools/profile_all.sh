@@ -1,34 +1,34 @@
-# Collect and summarise the tracked profiles on the GPU box in one gpurun call; summaries land in gpurun_out/profiles_r14 (copy them to profiles/).
+# Collect and summarise the tracked profiles on the GPU box in one gpurun call; summaries land in gpurun_out/profiles_r15 (copy them to profiles/).
 #   gpurun -- 'bash tools/profile_all.sh [frame] [train] [perop] [nav] [trained]'       (default: all five)
 set -e
-D=gpurun_out/profiles_r14
+D=gpurun_out/profiles_r15
 WHAT="${@:-frame train perop nav trained}"
 for w in $WHAT; do
   case $w in
     frame)
-      bash tools/profile_round.sh r14 full -- bench.py --steps 30 --warmup 5 --no-cpu
-      python tools/summarize_profiles.py r14 k_render_frame --dst $D --top 12 > gpurun_out/sum_r14.log 2>&1
-      rm -rf gpurun_out/r14_kt gpurun_out/r14_pmc? ;;
+      bash tools/profile_round.sh r15 full -- bench.py --steps 30 --warmup 5 --no-cpu --no-fit --frames-per-launch 1
+      python tools/summarize_profiles.py r15 k_render_frame --dst $D --top 12 > gpurun_out/sum_r15.log 2>&1
+      rm -rf gpurun_out/r15_kt gpurun_out/r15_pmc? ;;
     train)
-      bash tools/profile_round.sh r14_train short -- bench.py --mode train --steps 16 --warmup 4 --settle 64 --no-cpu
-      python tools/summarize_profiles.py r14_train k_grid_backward k_field_train_forward k_field_train_backward k_composite_train k_march_train k_dg_ --sources train --dst $D --top 30 \
+      bash tools/profile_round.sh r15_train short -- bench.py --mode train --steps 16 --warmup 4 --settle 64 --no-cpu
+      python tools/summarize_profiles.py r15_train k_gs_bin k_gs_accumulate k_field_train_forward k_field_train_backward k_composite_train k_march_train k_dg_ --sources train --dst $D --top 30 \
         --title "bench.py --mode train --steps 16 --warmup 4 --settle 64 (4,096-ray steps on the early, nearly full occupancy grid), 1x MI355X" > gpurun_out/sum_train.log 2>&1
-      rm -rf gpurun_out/r14_train_kt gpurun_out/r14_train_pmc? ;;
+      rm -rf gpurun_out/r15_train_kt gpurun_out/r15_train_pmc? ;;
     perop)
-      bash tools/profile_round.sh r14_perop short -- bench.py --path per_op --no-cpu --steps 8 --warmup 2
-      python tools/summarize_profiles.py r14_perop k_march_rays k_grid_forward k_ffmlp_forward k_composite_rays k_compact --dst $D --top 30 \
+      bash tools/profile_round.sh r15_perop short -- bench.py --path per_op --no-cpu --no-fit --frames-per-launch 1 --steps 8 --warmup 2
+      python tools/summarize_profiles.py r15_perop k_march_rays k_grid_forward k_ffmlp_forward k_composite_rays k_compact --dst $D --top 30 \
         --title "bench.py --path per_op (the reference-shaped op-by-op loop, 800x800, 64 iterations per frame), 1x MI355X" > gpurun_out/sum_perop.log 2>&1
-      rm -rf gpurun_out/r14_perop_kt gpurun_out/r14_perop_pmc? ;;
+      rm -rf gpurun_out/r15_perop_kt gpurun_out/r15_perop_pmc? ;;
     nav)
-      bash tools/profile_round.sh r14_nav short -- tools/time_nav.py --only filter_native,filter_frozen,planner_graphed
-      python tools/summarize_profiles.py r14_nav k_nav_run_bwd k_nav_run_fwd k_nav_density --dst $D --top 30 \
+      bash tools/profile_round.sh r15_nav short -- tools/time_nav.py --only filter_native,filter_frozen,planner_graphed
+      python tools/summarize_profiles.py r15_nav k_nav_run_bwd k_nav_run_fwd k_nav_density --dst $D --top 30 \
         --title "tools/time_nav.py: pose-filter iteration (run() 1,024 rays x 512 steps + backward) native and op-chain, planner query op-chain, 1x MI355X" > gpurun_out/sum_nav.log 2>&1
-      rm -rf gpurun_out/r14_nav_kt gpurun_out/r14_nav_pmc? ;;
+      rm -rf gpurun_out/r15_nav_kt gpurun_out/r15_nav_pmc? ;;
     trained)
-      bash tools/profile_round.sh r14_trained full -- bench.py --model trained --fit-steps 2000 --steps 10 --warmup 2 --no-cpu
-      python tools/summarize_profiles.py r14_trained k_render_frame --last 5 --dst $D --top 12 \
+      bash tools/profile_round.sh r15_trained full -- bench.py --model trained --fit-steps 2000 --steps 10 --warmup 2 --no-cpu --frames-per-launch 1
+      python tools/summarize_profiles.py r15_trained k_render_frame --last 5 --dst $D --top 12 \
         --title "bench.py --model trained --fit-steps 2000 (student fitted to the hand-set scene), 800x800, 1x MI355X" > gpurun_out/sum_trained.log 2>&1
-      rm -rf gpurun_out/r14_trained_kt gpurun_out/r14_trained_pmc? ;;
+      rm -rf gpurun_out/r15_trained_kt gpurun_out/r15_trained_pmc? ;;
   esac
 done
 du -sh gpurun_out
