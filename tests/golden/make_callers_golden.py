@@ -1,7 +1,7 @@
 """Golden vectors for the caller rows (provider) produced by EXECUTING THE REFERENCE'S OWN PYTHON.
 
 Build container only (needs /root/reference); run as `python -B tests/golden/make_callers_golden.py` from the repository root.
-Writes data only: tests/golden/callers_tier1.npz, callers_run.npz, callers_run_cuda.npz, callers_grid.npz.
+Writes data only: tests/golden/callers_tier1.npz, callers_run.npz, callers_run_cuda.npz, callers_grid.npz, callers_fields.npz.
 
 What executes, and what does not:
   * imported from /root/reference and run on the CPU: nerf/utils.py (get_rays :53-116, PSNRMeter :185-219), nerf/renderer.py
@@ -15,6 +15,10 @@ What executes, and what does not:
     (forward / density / color, nerf/renderer.py:103-112) are oracle.callers_oracle.DefaultField.
   So: the CONTROL FLOW AND TENSOR ARITHMETIC OF THE CALLERS is the reference's, executed; the leaf kernels under it are the
   oracle's (they stay "parity unpinned": the reference's CUDA cannot be built here).
+  * the field models: nerf/network.py and nerf/network_ff.py are imported and their NeRFNetwork.forward / density / color(mask) /
+    background run; `encoding.get_encoder` and `activation.trunc_exp` are the reference's; the modules `gridencoder`, `shencoder`, `ffmlp` they import are
+    module objects whose classes (constructor signatures of gridencoder/grid.py:94-106, shencoder/sphere_harmonics.py:62-73, ffmlp/ffmlp.py:100-122) compute
+    with the oracle (callers_oracle.grid_encode / sh_encode, a float32 F.linear chain over the reference's flat weight layout);
   * random numbers: get_rays / sample_pdf / run(perturb) draw from torch's global RNG -> the script records what was drawn
     (the product takes the same numbers as inputs).  update_extra_state draws `rand_like` / `randint`: those two functions are
     replaced, for the duration of the call, by readers of the pcg32 streams the native op uses (oracle.callers_oracle
@@ -116,9 +120,62 @@ def _oracle_raymarching():
     return m
 
 
+def _oracle_encoder_modules():
+    """modules `gridencoder`, `shencoder`, `ffmlp` for nerf/network*.py and encoding.get_encoder: the reference's class names and constructor
+    arguments, oracle arithmetic (float32 on the CPU)"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    g, sh, ff = types.ModuleType("gridencoder"), types.ModuleType("shencoder"), types.ModuleType("ffmlp")
+
+    class GridEncoder(nn.Module):                                    # gridencoder/grid.py:93-156
+        def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                     desired_resolution=None, gridtype="hash", align_corners=False):
+            super().__init__()
+            offsets, pls = O.grid_offsets(input_dim, num_levels, level_dim, per_level_scale, base_resolution, log2_hashmap_size, desired_resolution,
+                                          align_corners)
+            self.input_dim, self.num_levels, self.level_dim, self.per_level_scale = input_dim, num_levels, level_dim, pls
+            self.base_resolution, self.output_dim, self.gridtype_id, self.align_corners = base_resolution, num_levels * level_dim, {"hash": 0, "tiled": 1}[gridtype], align_corners
+            self.register_buffer("offsets", torch.from_numpy(offsets))
+            self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim).uniform_(-1e-4, 1e-4))
+
+        def forward(self, inputs, bound=1):
+            return CO.grid_encode(inputs.view(-1, self.input_dim), self.embeddings, self.offsets.tolist(), self.per_level_scale, self.base_resolution,
+                                  bound, self.gridtype_id, self.align_corners).view(list(inputs.shape[:-1]) + [self.output_dim])
+
+    class SHEncoder(nn.Module):                                      # shencoder/sphere_harmonics.py:61-87
+        def __init__(self, input_dim=3, degree=4):
+            super().__init__()
+            self.input_dim, self.degree, self.output_dim = input_dim, degree, degree ** 2
+
+        def forward(self, inputs, size=1):
+            x = inputs / size
+            return CO.sh_encode(x.view(-1, 3), self.degree).view(list(inputs.shape[:-1]) + [self.output_dim])
+
+    class FFMLP(nn.Module):                                          # ffmlp/ffmlp.py:99-168: flat weights [hidden,in] + (n-1) [hidden,hidden] + [16,hidden]
+        def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu"):
+            super().__init__()
+            assert activation == "relu" and output_dim <= 16
+            self.input_dim, self.output_dim, self.hidden_dim, self.num_layers, self.padded_output_dim = input_dim, output_dim, hidden_dim, num_layers, 16
+            self.weights = nn.Parameter(torch.zeros(hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + 16)))
+
+        def forward(self, inputs):
+            shapes = [(self.hidden_dim, self.input_dim)] + [(self.hidden_dim, self.hidden_dim)] * (self.num_layers - 1) + [(16, self.hidden_dim)]
+            h, off = inputs, 0
+            for k, (r, c) in enumerate(shapes):
+                h = F.linear(h, self.weights[off:off + r * c].view(r, c))
+                off += r * c
+                if k != len(shapes) - 1:
+                    h = F.relu(h)
+            return h[:, :self.output_dim]                            # ffmlp.py:166: outputs[:B, :self.output_dim]
+
+    g.GridEncoder, sh.SHEncoder, ff.FFMLP = GridEncoder, SHEncoder, FFMLP
+    return {"gridencoder": g, "shencoder": sh, "ffmlp": ff}
+
+
 def import_reference():
     _install_placeholders()
     sys.modules["raymarching"] = _oracle_raymarching()
+    sys.modules.update(_oracle_encoder_modules())
     sys.path.insert(0, REF)
     import nerf.provider as P
     import nerf.renderer as R
@@ -350,6 +407,9 @@ def tier2_run_cuda(R):
 
 def tier2_grid(R, H=32, seed=0):
     """update_extra_state (full sweep, then a partial one) and mark_untrained_grid on an H^3 grid"""
+    # one thread: `tmp_grid[cas, indices] = sigmas` (nerf/renderer.py:486,516) writes duplicate indices in an order that depends on the thread count;
+    # with one thread the LAST writer wins and the fixture is reproducible (the tests accept any writer on those cells)
+    torch.set_num_threads(1)
     model, field = oracle_field()
     ren = small_grid(make_renderer(R, field, bound=W.BOUND, cuda_ray=True, min_near=0.2, density_thresh=10), H)
     cas = ren.cascade
@@ -405,6 +465,62 @@ def tier2_grid(R, H=32, seed=0):
         ren.update_extra_state(decay=0.95, S=H)
     out["partial_grid"], out["partial_bitfield"] = ren.density_grid.numpy().copy(), ren.density_bitfield.numpy().copy()
     out["partial_mean_density"] = np.float64(ren.mean_density)
+    torch.set_num_threads(8)
+    return out
+
+
+def tier3_fields():
+    """NeRFNetwork of nerf/network.py (M1: bias-free Linear layers, optional background model) and of nerf/network_ff.py (M2: FFMLP wiring)"""
+    import nerf.network as NW
+    import nerf.network_ff as NF
+    assert NW.__file__.startswith(REF) and NF.__file__.startswith(REF)
+    model = W.make_model(0)
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-2, 2, (3000, 3)).astype(np.float32)
+    x[:5] = [[2, 2, 2], [-2, -2, -2], [0, 0, 0], [2, -2, 0.5], [0, 0, -2]]
+    d = rng.normal(size=(3000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    mask = rng.uniform(size=3000) < 0.3
+    out = {"x": x, "d": d, "mask": mask}
+    # ---- M1: the default network, with its background model
+    net = NW.NeRFNetwork(bound=W.BOUND, cuda_ray=False, bg_radius=3.0).eval()
+    shapes = [tuple(l.weight.shape) for l in list(net.sigma_net) + list(net.color_net) + list(net.bg_net)]
+    assert shapes == [(64, 32), (16, 64), (64, 31), (64, 64), (3, 64), (64, 24), (3, 64)], shapes
+    with torch.no_grad():
+        net.encoder.embeddings.copy_(torch.from_numpy(model["embeddings"]))
+        net.encoder_bg.embeddings.copy_(torch.from_numpy(np.random.default_rng(22).uniform(-1, 1, tuple(net.encoder_bg.embeddings.shape)).astype(np.float32)))
+        for k, l in enumerate(list(net.sigma_net) + list(net.color_net) + list(net.bg_net)):
+            w = rng.uniform(-0.4, 0.4, tuple(l.weight.shape)).astype(np.float32)
+            l.weight.copy_(torch.from_numpy(w))
+            out[f"m1_w{k}"] = w
+    out["m1_bg_table_seed"], out["m1_bg_table_shape"] = np.int64(22), np.array(net.encoder_bg.embeddings.shape)
+    out["m1_offsets"], out["m1_bg_offsets"] = net.encoder.offsets.numpy(), net.encoder_bg.offsets.numpy()
+    out["m1_per_level_scale"], out["m1_bg_per_level_scale"] = np.float64(net.encoder.per_level_scale), np.float64(net.encoder_bg.per_level_scale)
+    tx, td = torch.from_numpy(x), torch.from_numpy(d)
+    with torch.no_grad():
+        sigma, color = net(tx, td)
+        dens = net.density(tx)
+        cm = net.color(tx, td, mask=torch.from_numpy(mask), **dens)
+        sph = torch.from_numpy(O.sph_from_ray(x * 0.1, d, 3.0))
+        bg = net.background(sph, td)
+    out.update(m1_sigma=_np(sigma), m1_color=_np(color), m1_density_sigma=_np(dens["sigma"]), m1_geo_feat=_np(dens["geo_feat"]), m1_color_masked=_np(cm),
+               m1_sph=_np(sph), m1_background=_np(bg), m1_n_param_groups=np.int64(len(net.get_params(1e-2))))
+    # gradient of a weighted sum w.r.t. the points (the nav loop differentiates density w.r.t. x: simulate.py:343, nav/quad_plot.py:237)
+    xg = tx.clone().requires_grad_(True)
+    out["m1_w_sum"] = rng.uniform(0.5, 1.5, 3000).astype(np.float32)
+    (net.density(xg)["sigma"] * torch.from_numpy(out["m1_w_sum"])).sum().backward()
+    out["m1_grad_x"] = _np(xg.grad)
+    # ---- M2: the FFMLP network with the hand-set S-ring model
+    nf = NF.NeRFNetwork(bound=W.BOUND, cuda_ray=False).eval()
+    assert nf.in_dim_color == 32 and nf.sigma_net.weights.numel() == 7168 and nf.color_net.weights.numel() == 11264
+    with torch.no_grad():
+        nf.encoder.embeddings.copy_(torch.from_numpy(model["embeddings"]))
+        nf.sigma_net.weights.copy_(torch.from_numpy(model["sigma_weights"]))
+        nf.color_net.weights.copy_(torch.from_numpy(model["color_weights"]))
+        sigma, rgb = nf(tx, td)
+        dens = nf.density(tx)
+        cm = nf.color(tx, td, mask=torch.from_numpy(mask), **dens)
+    out.update(m2_sigma=_np(sigma), m2_rgb=_np(rgb), m2_geo_feat=_np(dens["geo_feat"]), m2_color_masked=_np(cm))
     return out
 
 
@@ -413,7 +529,7 @@ def main():
     torch.set_num_threads(8)
     O.set_threads(8)
     for name, fn in (("callers_tier1", lambda: tier1(U, R, P)), ("callers_run", lambda: tier2_run(R)),
-                     ("callers_run_cuda", lambda: tier2_run_cuda(R)), ("callers_grid", lambda: tier2_grid(R))):
+                     ("callers_run_cuda", lambda: tier2_run_cuda(R)), ("callers_grid", lambda: tier2_grid(R)), ("callers_fields", tier3_fields)):
         data = fn()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)

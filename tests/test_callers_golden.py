@@ -302,3 +302,55 @@ def test_oracle_mark_untrained_grid_against_reference():
     unseen = np.unpackbits(g["mark_unseen"]).astype(bool)[:cas * H ** 3].reshape(cas, -1)
     assert 0 < unseen.sum() < unseen.size
     np.testing.assert_array_equal(grid < 0, unseen)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# tier 3: the field models (M1 nerf/network.py, M2 nerf/network_ff.py), executed
+# ------------------------------------------------------------------------------------------------------------------------
+def _m1_oracle(g):
+    model = W.make_model(0)
+    w = [g[f"m1_w{k}"] for k in range(7)]
+    fld = CO.DefaultField(model["embeddings"], g["m1_offsets"], float(g["m1_per_level_scale"]), w[0:2], w[2:5], W.BOUND)
+    shape = tuple(int(v) for v in g["m1_bg_table_shape"])
+    bg_table = np.random.default_rng(int(g["m1_bg_table_seed"])).uniform(-1, 1, shape).astype(np.float32)
+    return fld, bg_table, w[5:7]
+
+
+def test_oracle_default_field_against_reference_network():
+    """M1: oracle.callers_oracle.DefaultField == NeRFNetwork of nerf/network.py:95-191 executed (encoding.get_encoder, trunc_exp and the layer wiring are the
+    reference's; the encoders under it the oracle's): forward, density, color(mask), background and d sigma / d x -- bit-exact except the background's 2-D grid,
+    which the oracle evaluates through its C restatement (float32, another summation order: 2e-6)."""
+    g = gold("callers_fields")
+    fld, bg_table, bg_w = _m1_oracle(g)
+    x, d, mask = torch.from_numpy(g["x"]), torch.from_numpy(g["d"]), torch.from_numpy(g["mask"])
+    with torch.no_grad():
+        sigma, color = fld(x, d)
+        dens = fld.density(x)
+        cm = fld.color(x, d, mask=mask, **dens)
+        bg = fld.background(torch.from_numpy(g["m1_sph"]), d, bg_table, g["m1_bg_offsets"], float(g["m1_bg_per_level_scale"]), bg_w)
+    np.testing.assert_array_equal(sigma.numpy(), g["m1_sigma"])
+    np.testing.assert_array_equal(color.numpy(), g["m1_color"])
+    np.testing.assert_array_equal(dens["sigma"].numpy(), g["m1_density_sigma"])
+    np.testing.assert_array_equal(dens["geo_feat"].numpy(), g["m1_geo_feat"])
+    np.testing.assert_array_equal(cm.numpy(), g["m1_color_masked"])
+    assert np.all(g["m1_color_masked"][~g["mask"]] == 0) and int(g["m1_n_param_groups"]) == 6
+    assert np.max(np.abs(bg.numpy() - g["m1_background"])) < 2e-6
+    np.testing.assert_array_equal(O.sph_from_ray(g["x"] * 0.1, g["d"], 3.0), g["m1_sph"])
+
+
+def test_oracle_ff_field_against_reference_network_ff():
+    """M2: DefaultField(ff_layout=True) == NeRFNetwork of nerf/network_ff.py:51-134 executed (colour input cat(SH16, geo15, 0) = 32 wide, outputs [:, :3],
+    sigma net output 16 wide of which [0] is the logit): bit-exact"""
+    g = gold("callers_fields")
+    model = W.make_model(0)
+    sw, cw = ff_model_matrices(model)
+    fld = CO.DefaultField(model["embeddings"], model["offsets"], model["per_level_scale"], sw, cw, model["bound"], ff_layout=True)
+    x, d, mask = torch.from_numpy(g["x"]), torch.from_numpy(g["d"]), torch.from_numpy(g["mask"])
+    with torch.no_grad():
+        sigma, rgb = fld(x, d)
+        dens = fld.density(x)
+        cm = fld.color(x, d, mask=mask, **dens)
+    np.testing.assert_array_equal(sigma.numpy(), g["m2_sigma"])
+    np.testing.assert_array_equal(rgb.numpy(), g["m2_rgb"])
+    np.testing.assert_array_equal(dens["geo_feat"].numpy(), g["m2_geo_feat"])
+    np.testing.assert_array_equal(cm.numpy(), g["m2_color_masked"])

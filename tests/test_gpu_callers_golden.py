@@ -272,3 +272,57 @@ def test_mark_untrained_grid_against_reference(linear_field, dev):
     ren.mark_untrained_grid(g["mark_poses"], g["mark_intrinsics"])
     unseen = np.unpackbits(g["mark_unseen"]).astype(bool)[:cas * H ** 3].reshape(cas, -1)
     np.testing.assert_array_equal(ren.density_grid.cpu().numpy() < 0, unseen)
+
+
+def test_default_field_on_gpu_against_reference_network(dev, model):
+    """M1 / N1: ngp.field.NGPField (hash grid + SH + bias-free nn.Linear layers on the drop-in ops) == NeRFNetwork of nerf/network.py executed on the CPU:
+    sigma 2e-5 relative (float32, 32- and 64-term dot products in other orders, exp amplifies), geo_feat 5e-6, rgb 2e-6, color(mask), the background model
+    1e-5, and d sigma / d x (the planner's gradient, nav/quad_plot.py:237) 1e-4 in norm."""
+    from ngp.field import NGPField
+    g = gold("callers_fields")
+    field = NGPField(bound=model["bound"], bg_radius=3.0).to(dev)
+    assert len(field.get_params(1e-2)) == int(g["m1_n_param_groups"])
+    assert np.array_equal(field.encoder.offsets.cpu().numpy(), g["m1_offsets"]) and np.array_equal(field.encoder_bg.offsets.cpu().numpy(), g["m1_bg_offsets"])
+    shape = tuple(int(v) for v in g["m1_bg_table_shape"])
+    with torch.no_grad():
+        field.encoder.embeddings.copy_(t(model["embeddings"], dev))
+        field.encoder_bg.embeddings.copy_(t(np.random.default_rng(int(g["m1_bg_table_seed"])).uniform(-1, 1, shape).astype(np.float32), dev))
+        for k, layer in enumerate(list(field.sigma_net) + list(field.color_net) + list(field.bg_net)):
+            layer.weight.copy_(t(g[f"m1_w{k}"], dev))
+    x, d, mask = t(g["x"], dev), t(g["d"], dev), t(g["mask"], dev)
+    with torch.no_grad():
+        sigma, color = field(x, d)
+        dens = field.density(x)
+        cm = field.color(x, d, mask=mask, **dens)
+        bg = field.background(t(g["m1_sph"], dev), d)
+    assert np.max(np.abs(sigma.cpu().numpy() - g["m1_sigma"]) / g["m1_sigma"]) < 2e-5
+    assert np.max(np.abs(dens["geo_feat"].cpu().numpy() - g["m1_geo_feat"])) < 5e-6
+    assert np.max(np.abs(color.cpu().numpy() - g["m1_color"])) < 2e-6
+    assert np.max(np.abs(cm.cpu().numpy() - g["m1_color_masked"])) < 2e-6 and np.all(cm.cpu().numpy()[~g["mask"]] == 0)
+    assert np.max(np.abs(bg.cpu().numpy() - g["m1_background"])) < 1e-5
+    xg = x.clone().requires_grad_(True)
+    w_sum = g["m1_w_sum"]
+    (field.density(xg)["sigma"] * t(w_sum, dev)).sum().backward()
+    assert rel(xg.grad.cpu().numpy(), g["m1_grad_x"]) < 1e-4
+
+
+def test_ff_field_on_gpu_against_reference_network_ff(dev, ff_field):
+    """M2: ngp.field.NGPFieldFF under autocast (per op and as one launch) == NeRFNetwork of nerf/network_ff.py executed in float32 on the CPU with the same master
+    weights: half activations -> sigma 5e-3 relative, rgb 4e-3, color(mask) likewise"""
+    g = gold("callers_fields")
+    x, d, mask = t(g["x"], dev), t(g["d"], dev), t(g["mask"], dev)
+    ff_field.fused_inference = False
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = ff_field(x, d)
+            dens = ff_field.density(x)
+            cm = ff_field.color(x, d, mask=mask, **dens)
+    finally:
+        ff_field.fused_inference = True
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        sigma1, rgb1 = ff_field(x, d)                                   # the one-launch route an unmodified renderer gets
+    for s_, c_ in ((sigma, rgb), (sigma1, rgb1)):
+        assert np.max(np.abs(s_.float().cpu().numpy() - g["m2_sigma"]) / g["m2_sigma"]) < 5e-3
+        assert np.max(np.abs(c_.float().cpu().numpy() - g["m2_rgb"])) < 4e-3
+    assert np.max(np.abs(cm.float().cpu().numpy() - g["m2_color_masked"])) < 4e-3 and np.all(cm.cpu().numpy()[~g["mask"]] == 0)
+    assert np.max(np.abs(dens["geo_feat"].float().cpu().numpy() - g["m2_geo_feat"])) < 2e-2
