@@ -308,7 +308,7 @@ def test_default_field_on_gpu_against_reference_network(dev, model):
 
 def test_ff_field_on_gpu_against_reference_network_ff(dev, ff_field):
     """M2: ngp.field.NGPFieldFF under autocast (per op and as one launch) == NeRFNetwork of nerf/network_ff.py executed in float32 on the CPU with the same master
-    weights: half activations -> sigma 5e-3 relative, rgb 4e-3, color(mask) likewise"""
+    weights: half activations -> sigma 1.5e-2 relative (exp of a half logit, plus the half hidden layers), rgb 4e-3, color(mask) likewise"""
     g = gold("callers_fields")
     x, d, mask = t(g["x"], dev), t(g["d"], dev), t(g["mask"], dev)
     ff_field.fused_inference = False
@@ -322,7 +322,7 @@ def test_ff_field_on_gpu_against_reference_network_ff(dev, ff_field):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         sigma1, rgb1 = ff_field(x, d)                                   # the one-launch route an unmodified renderer gets
     for s_, c_ in ((sigma, rgb), (sigma1, rgb1)):
-        assert np.max(np.abs(s_.float().cpu().numpy() - g["m2_sigma"]) / g["m2_sigma"]) < 5e-3
+        assert np.max(np.abs(s_.float().cpu().numpy() - g["m2_sigma"]) / g["m2_sigma"]) < 1.5e-2    # the logit is a half: one ulp at 4.1 is 0.4 %
         assert np.max(np.abs(c_.float().cpu().numpy() - g["m2_rgb"])) < 4e-3
     assert np.max(np.abs(cm.float().cpu().numpy() - g["m2_color_masked"])) < 4e-3 and np.all(cm.cpu().numpy()[~g["mask"]] == 0)
     assert np.max(np.abs(dens["geo_feat"].float().cpu().numpy() - g["m2_geo_feat"])) < 2e-2

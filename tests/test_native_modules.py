@@ -121,3 +121,37 @@ def test_shims_compute_the_same_bits_as_the_ctypes_path(dev, oracle):
     ff.ffmlp_inference(xin, net.weights.detach().half(), 256, 32, 16, 64, 2, 0, 6, torch.empty(1, device=dev, dtype=torch.half), outm)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         assert torch.equal(outm, net(xin))
+
+
+@pytest.mark.gpu
+def test_raymarching_shim_refuses_wrong_dtypes_and_short_tensors(dev):
+    """the `_raymarching` module checks scalar types and sizes (the reference's entry points check nothing and dispatch on the dtype; these
+    kernels are float32 / int32 / uint8 only): a half, double or int64 tensor, or one that is too short, is a RuntimeError, not reinterpreted memory."""
+    rm = load("_raymarching")
+    N = 64
+    o, d = torch.rand(N, 3, device=dev), torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=1)
+    aabb = torch.tensor([-2.0, -2, -2, 2, 2, 2], device=dev)
+    nears, fars = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    rm.near_far_from_aabb(o, d, aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="rays_d must be Float"):
+        rm.near_far_from_aabb(o, d.double(), aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="nears has 32 elements"):
+        rm.near_far_from_aabb(o, d, aabb, N, 0.2, nears[:32].contiguous(), fars)
+    idx = torch.empty(N, dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="coords must be Int"):
+        rm.morton3D(torch.zeros(N, 3, dtype=torch.int64, device=dev), N, idx)
+    M = N * 2 + 128
+    sig, rgb, dl = torch.rand(M, device=dev), torch.rand(M, 3, device=dev), torch.rand(M, 2, device=dev)
+    alive, rt = torch.arange(N, dtype=torch.int32, device=dev), nears.clone()
+    ws, dep, img = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+    rm.composite_rays(N, 2, alive, rt, sig, rgb, dl, ws, dep, img)
+    with pytest.raises(RuntimeError, match="rgbs must be Float"):                       # what the autocast field returns: the wrapper casts, a direct caller must
+        rm.composite_rays(N, 2, alive, rt, sig, rgb.half(), dl, ws, dep, img)
+    with pytest.raises(RuntimeError, match="sigmas has"):
+        rm.composite_rays(N, 2, alive, rt, sig[:N].contiguous(), rgb, dl, ws, dep, img)
+    bitfield = torch.full((2 * 128 ** 3 // 8,), 255, dtype=torch.uint8, device=dev)
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+    with pytest.raises(RuntimeError, match="xyzs must be"):
+        rm.march_rays(N, 8, alive, rt, o, d, 2.0, 0.0, 1024, 2, 128, bitfield, nears, fars, xyzs, dirs, deltas, 0)      # M = 256 < n_alive * n_step = 512
+    with pytest.raises(RuntimeError, match="grid must be Byte"):
+        rm.march_rays(N, 2, alive, rt, o, d, 2.0, 0.0, 1024, 2, 128, bitfield.float(), nears, fars, xyzs, dirs, deltas, 0)
