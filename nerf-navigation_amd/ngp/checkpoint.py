@@ -29,10 +29,12 @@ def read_checkpoint(path):
 
 def read_checkpoint_full(path):
     """-> (model state dict, extra): `extra` holds the scalars the reference's Trainer.save_checkpoint stores beside the model
-    (nerf/utils.py:944-953) and load_checkpoint restores into it (:1018-1022): mean_count, mean_density, epoch, global_step."""
+    (nerf/utils.py:944-953) and load_checkpoint restores into it (:1018-1022): mean_count, mean_density, epoch, global_step, and -- in a full
+    checkpoint (:955-958, :1024-1025) -- `ema`, torch_ema's state dict {decay, num_updates, shadow_params, collected_params}, whose parameter
+    order is the model's; `ngp.train.WeightEMA.load_state_dict` takes it as it is."""
     blob = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(blob, dict) and "model" in blob:
-        return blob["model"], {k: blob[k] for k in ("mean_count", "mean_density", "epoch", "global_step") if k in blob}
+        return blob["model"], {k: blob[k] for k in ("mean_count", "mean_density", "epoch", "global_step", "ema") if k in blob}
     return blob, {}
 
 

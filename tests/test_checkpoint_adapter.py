@@ -79,6 +79,15 @@ def test_reference_state_dict_split_and_file_round_trip(tmp_path):
     CK.load_renderer_buffers(r, CK.split_state_dict(model)[1], extra)
     assert r.mean_count == 73211 and r.mean_density == 0.0625 and torch.equal(r.density_bitfield, sd["density_bitfield"])
     assert CK.read_checkpoint_full(str(path))[1] == {"epoch": 1}
+    # a full checkpoint also carries torch_ema's state (nerf/utils.py:955-958): it loads into WeightEMA as it is
+    from ngp.train import WeightEMA
+    params = [torch.nn.Parameter(sd["encoder.embeddings"].clone()), torch.nn.Parameter(sd["sigma_net.0.weight"].clone())]
+    shadow = [p.detach() * 0.5 for p in params]
+    torch.save({"model": sd, "epoch": 7, "ema": {"decay": 0.95, "num_updates": 12, "shadow_params": shadow, "collected_params": None}}, tmp_path / "full.pth")
+    _, extra = CK.read_checkpoint_full(str(tmp_path / "full.pth"))
+    ema = WeightEMA(params, decay=0.5)
+    ema.load_state_dict(extra["ema"])
+    assert ema.decay == 0.95 and ema.num_updates == 12 and all(torch.equal(a, b) for a, b in zip(ema.shadow, shadow))
 
 
 @pytest.mark.gpu
