@@ -210,6 +210,13 @@ size_t ngp_grid_scatter_binned_workspace(uint32_t B, uint32_t L);
 int ngp_grid_scatter_binned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                             uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
                             int out_dtype, float out_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The same in two steps: phase 1 bins all levels (grad_embeddings unused), phase 2 sums levels [level_lo, level_hi) into their rows of grad_embeddings;
+ * any number of phase-2 calls after one phase-1 call (same workspace, same stream).  Lets the data-parallel gradient exchange all-reduce one group of
+ * levels while the next is summed.  B <= 2^22. */
+int ngp_grid_scatter_binned_phase(int phase, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                  uint32_t B, uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H, uint32_t max_level_rows,
+                                  uint32_t gridtype, int align_corners, int out_dtype, float out_scale, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* _shencoder  (reference: shencoder/src/shencoder.h:10,13)                  */

@@ -848,10 +848,10 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
 
 // the (level, slice) of ticket t, levels from the finest down so that the large hashed levels start first.  Evaluated by one wave: lane l
 // holds level L-1-l (L <= 32), an inclusive scan of the slice counts finds the level in one step instead of a 16-deep chain of loads.
-__device__ __forceinline__ uint32_t gs_decode_wave(const int* __restrict__ offsets, uint32_t L, uint32_t t, uint32_t lane) {
+__device__ __forceinline__ uint32_t gs_decode_wave(const int* __restrict__ offsets, uint32_t level_lo, uint32_t L, uint32_t t, uint32_t lane) {
     uint32_t n = 0;
-    const int l = (int)L - 1 - (int)lane;
-    if (l >= 0) {
+    const int l = (int)L - 1 - (int)lane;              // levels [level_lo, L): the caller may sum the table one group of levels at a time
+    if (l >= (int)level_lo) {
         const uint32_t rows = (uint32_t)(offsets[l + 1] - offsets[l]);
         const uint32_t sh = gs_shift(rows);
         n = (rows + (1u << sh) - 1) >> sh;
@@ -863,7 +863,7 @@ __device__ __forceinline__ uint32_t gs_decode_wave(const int* __restrict__ offse
         const uint32_t o = __shfl_up(incl, off, 64);
         if ((int)lane >= off) incl += o;
     }
-    const unsigned long long hit = __ballot(l >= 0 && t < incl);     // first lane whose inclusive count exceeds t
+    const unsigned long long hit = __ballot(l >= (int)level_lo && t < incl);     // first lane whose inclusive count exceeds t
     if (hit == 0ull) return 0xFFFFFFFFu;
     const int first = __ffsll((long long)hit) - 1;
     const uint32_t before = __shfl(incl - n, first, 64);
@@ -873,7 +873,8 @@ __device__ __forceinline__ uint32_t gs_decode_wave(const int* __restrict__ offse
 template <typename OUT_T>
 __global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restrict__ g_vals, const uint16_t* __restrict__ g_rows,
                                                         const uint16_t* __restrict__ g_dir, const int* __restrict__ offsets, uint32_t* ticket,
-                                                        OUT_T* __restrict__ out, uint32_t L, uint32_t nchunks, float out_scale, bool add_to_out) {
+                                                        OUT_T* __restrict__ out, uint32_t level_lo, uint32_t L, uint32_t nchunks, float out_scale,
+                                                        bool add_to_out) {
     extern __shared__ unsigned long long s_acc[];      // [GS_SLICE_ROWS][2] 64-bit fixed point (units of 2^-24)
     __shared__ uint32_t s_ticket, s_poison;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, sub = lane >> 4, l16 = lane & 15u;
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restri
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(ticket, 1u);
             t = __shfl(t, 0, 64);
-            const uint32_t code = gs_decode_wave(offsets, L, t, lane);
+            const uint32_t code = gs_decode_wave(offsets, level_lo, L, t, lane);
             if (lane == 0) { s_ticket = code; s_poison = 0u; }
         }
         __syncthreads();
@@ -944,16 +945,19 @@ extern "C" size_t ngp_grid_scatter_binned_workspace(uint32_t B, uint32_t L) {
     return gs_layout(B, L).total;
 }
 
-extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
-                                       uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
-                                       int out_dtype, float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
-    NGP_REQUIRE(offsets && grad_embeddings && (B == 0 || (grad && inputs)), "grid_scatter_binned: null pointer");
-    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "grid_scatter_binned: L must be in 1..32");
-    NGP_REQUIRE(out_dtype == NGP_F32 || out_dtype == NGP_F16, "grid_scatter_binned: out_dtype must be f32 or f16");
+static int gs_run(const char* who, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t L, float S, uint32_t H,
+                  uint32_t max_level_rows, uint32_t gridtype, int align_corners, int out_dtype, float out_scale, bool do_bin, bool do_sum, uint32_t level_lo,
+                  uint32_t level_hi, void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(offsets && (!do_sum || grad_embeddings) && (B == 0 || !do_bin || (grad && inputs)), "%s: null pointer", who);
+    NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "%s: L must be in 1..32", who);
+    NGP_REQUIRE(level_lo < level_hi && level_hi <= L, "%s: bad level range", who);
+    NGP_REQUIRE(out_dtype == NGP_F32 || out_dtype == NGP_F16, "%s: out_dtype must be f32 or f16", who);
     NGP_REQUIRE(max_level_rows >= 1 && max_level_rows <= GS_MAX_SLICES * GS_SLICE_ROWS,
-                "grid_scatter_binned: a level may have at most 2^19 rows (use grid_encode_backward for larger tables)");
+                "%s: a level may have at most 2^19 rows (use grid_encode_backward for larger tables)", who);
+    const bool split = !(do_bin && do_sum && level_lo == 0 && level_hi == L);
+    NGP_REQUIRE(!split || B <= GS_PASS_SAMPLES, "%s: binning and summing in separate calls needs B <= 2^22 samples (one pass)", who);
     const gs_ws w = gs_layout(B, L);
-    NGP_REQUIRE(workspace && workspace_bytes >= w.total, "grid_scatter_binned: workspace too small (see ngp_grid_scatter_binned_workspace)");
+    NGP_REQUIRE(workspace && workspace_bytes >= w.total, "%s: workspace too small (see ngp_grid_scatter_binned_workspace)", who);
     hipStream_t s = (hipStream_t)stream;
     ge_levels lv;
     ge_fill_levels(lv, L, S, H);
@@ -963,7 +967,7 @@ extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, co
     if (!lds_ok) {
         if (hipFuncSetAttribute((const void*)k_gs_accumulate<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_gs_accumulate<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ngp_fail(NGP_ELAUNCH, "grid_scatter_binned: cannot reserve %zu bytes of LDS", lds);
+            return ngp_fail(NGP_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
         lds_ok = true;
     }
     int cus = 256;
@@ -973,19 +977,42 @@ extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, co
     do {                                               // B == 0: one pass that writes zeros (the whole table is always written)
         const uint32_t count = B - first < GS_PASS_SAMPLES ? B - first : GS_PASS_SAMPLES;
         const uint32_t nchunks = count ? ngp_div_up(count, GS_CHUNK) : 0u;
-        if (hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "grid_scatter_binned: memset failed");
-        if (nchunks)
+        if (do_bin && nchunks)
             hipLaunchKernelGGL(k_gs_bin, dim3(nchunks, L), dim3(GS_CHUNK), 0, s, (const _Float16*)grad, inputs, offsets, (uint32_t*)(base + w.vals),
                                (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0);
-        if (out_dtype == NGP_F32)
-            hipLaunchKernelGGL(k_gs_accumulate<float>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
-                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (float*)grad_embeddings, L, nchunks, out_scale, add);
-        else
-            hipLaunchKernelGGL(k_gs_accumulate<_Float16>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
-                               (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (_Float16*)grad_embeddings, L, nchunks, out_scale, add);
+        if (do_sum) {
+            if (hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "%s: memset failed", who);
+            if (out_dtype == NGP_F32)
+                hipLaunchKernelGGL(k_gs_accumulate<float>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
+                                   (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (float*)grad_embeddings, level_lo, level_hi, nchunks,
+                                   out_scale, add);
+            else
+                hipLaunchKernelGGL(k_gs_accumulate<_Float16>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
+                                   (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (_Float16*)grad_embeddings, level_lo, level_hi, nchunks,
+                                   out_scale, add);
+        }
         first += count;
         add = true;
     } while (first < B);
-    NGP_CHECK_LAUNCH("grid_scatter_binned");
+    NGP_CHECK_LAUNCH(who);
     return NGP_OK;
+}
+
+extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                       uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
+                                       int out_dtype, float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return gs_run("grid_scatter_binned", grad, inputs, offsets, grad_embeddings, B, L, S, H, max_level_rows, gridtype, align_corners, out_dtype, out_scale,
+                  true, true, 0, L, workspace, workspace_bytes, stream);
+}
+
+// The same in two steps, for a caller that wants the table one GROUP OF LEVELS at a time (the data-parallel gradient exchange starts the all-reduce
+// of a group's rows while the next group is summed): phase 1 bins all levels (grad_embeddings unused), phase 2 sums levels [level_lo, level_hi) into
+// their rows of grad_embeddings; any number of phase-2 calls over one phase-1 call, same workspace, same stream order.  B <= 2^22.
+extern "C" int ngp_grid_scatter_binned_phase(int phase, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                             uint32_t B, uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H, uint32_t max_level_rows,
+                                             uint32_t gridtype, int align_corners, int out_dtype, float out_scale, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+    NGP_REQUIRE(phase == 1 || phase == 2, "grid_scatter_binned_phase: phase must be 1 (bin) or 2 (sum a group of levels)");
+    return gs_run("grid_scatter_binned_phase", grad, inputs, offsets, grad_embeddings, B, L, S, H, max_level_rows, gridtype, align_corners, out_dtype, out_scale,
+                  phase == 1, phase == 2, phase == 1 ? 0u : level_lo, phase == 1 ? L : level_hi, workspace, workspace_bytes, stream);
 }

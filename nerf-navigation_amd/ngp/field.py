@@ -114,7 +114,9 @@ class _field_train(Function):
                 # atomics, no widening), or, for the exchange, as a half tensor scaled by 1 / world size (half the bytes on the links)
                 grad_emb = G.table_gradient_binned(grad_enc, inputs, enc.offsets, M, enc.num_levels, S, enc.base_resolution, enc.gridtype_id,
                                                    enc.align_corners, out_dtype=torch.float16 if sink is not None else torch.float32,
-                                                   out_scale=(1.0 / sink.world_size()) if sink is not None else 1.0)
+                                                   out_scale=(1.0 / sink.world_size()) if sink is not None else 1.0,
+                                                   on_group=(lambda out, r0, r1: sink.deliver_rows(enc.embeddings, out, r0, r1)) if sink is not None else None)
+                delivered_table = sink is not None       # group by group, finest levels first: their all-reduce runs while the coarser ones are summed
             else:
                 grad_emb = torch.zeros_like(emb_half)
                 dummy = torch.empty(1, dtype=torch.float16, device=x.device)
@@ -123,9 +125,10 @@ class _field_train(Function):
                                                           M, 3, enc.level_dim, enc.num_levels, S, enc.base_resolution, 0,
                                                           _hip.ptr(dummy), _hip.ptr(dummy), enc.gridtype_id, int(enc.align_corners), _hip.F16, _hip.stream()),
                                "grid_encode_backward")
+                delivered_table = False
                 if sink is not None:
                     grad_emb.mul_(1.0 / sink.world_size())
-            if sink is not None:
+            if sink is not None and not delivered_table:
                 sink.deliver(enc.embeddings, grad_emb)
         if sink is not None:
             return None, None, None, None, None, None

@@ -40,7 +40,8 @@ class GradExchange:
         self.big = [p for p in self.params if p.numel() >= big_numel]
         self.small = [p for p in self.params if p.numel() < big_numel]
         self.bucket = None
-        self.pending = []                  # (param, delivered tensor, work handle)
+        self.pending = []                  # (params, delivered tensor, work handle)
+        self.partial = {}                  # id(param) -> (param, full gradient tensor, work handles of its row groups)
         self.timing = timing
         self.stats = {"allreduce_bytes": 0, "exposed_ms": None}
         self._events = None
@@ -61,8 +62,32 @@ class GradExchange:
         self.stats["allreduce_bytes"] += grad.numel() * grad.element_size()
         self.pending.append((params, grad, work))
 
+    def deliver_rows(self, param, full, row_lo, row_hi):
+        """rows [row_lo, row_hi) of `full` (this rank's whole gradient of `param`, pre-divided by the world size, any float dtype) are final: start their
+        all-reduce.  The native scatter hands the table over one group of levels at a time (gridencoder.grid.table_gradient_binned(on_group=...)), so
+        the collective of one group runs while the next is still being summed; only the last, smallest group (the coarsest levels) is exposed."""
+        if row_hi <= row_lo:
+            return
+        piece = full[row_lo:row_hi]
+        work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+        self.stats["allreduce_bytes"] += piece.numel() * piece.element_size()
+        entry = self.partial.setdefault(id(param), (param, full, []))
+        assert entry[1] is full, "deliver_rows: one gradient tensor per parameter and step"
+        entry[2].append(work)
+
     def _finish_pending(self):
         delivered = set()
+        for param, full, works in self.partial.values():
+            for work in works:
+                work.wait()
+            g = full.view_as(param)
+            param_grad = g.to(param.dtype) if g.dtype != param.dtype else g
+            if param.grad is None:
+                param.grad = param_grad
+            else:
+                param.grad.copy_(param_grad)
+            delivered.add(id(param))
+        self.partial = {}
         for params, grad, work in self.pending:
             work.wait()                    # on the GPU: makes the current stream wait for the collective; the host does not block
             flat, off = grad.reshape(-1), 0
@@ -82,7 +107,7 @@ class GradExchange:
     def __call__(self):
         rank, world = sharding.world()
         if not sharding.collectives_on():
-            self.pending = []
+            self.pending, self.partial = [], {}
             return
         if self.timing and torch.cuda.is_available():
             self._events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -57,6 +57,7 @@ _SIGNATURES = {
                                          c_vp, c_vp, c_u32, c_int, c_int, c_vp]),
     "ngp_grid_scatter_binned_workspace": (c_sz, [c_u32, c_u32]),
     "ngp_grid_scatter_binned": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_u32, c_u32, c_u32, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
+    "ngp_grid_scatter_binned_phase": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_u32, c_u32, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
     "ngp_sh_encode_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_int, c_vp, c_vp]),
     "ngp_sh_encode_backward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_freq_encode_forward": (c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp]),

@@ -98,3 +98,34 @@ def test_grid_encoder_module_uses_the_binned_scatter_under_autocast(dev):
     assert grads[True].dtype == torch.float32
     assert float((grads[True] - grads[False]).abs().max()) <= 4e-3 * float(grads[False].abs().max())
     assert float(grads[True].abs().max()) > 0
+
+
+def test_binned_scatter_in_level_groups_equals_one_call(oracle, dev):
+    """ngp_grid_scatter_binned_phase: bin once, then sum the table one group of levels at a time (what the gradient exchange uses to overlap its
+    all-reduces): the sums are exact and order-independent, so the result equals the single call BIT FOR BIT; the callback sees contiguous row
+    ranges that cover the table once, finest levels first."""
+    from gridencoder import grid as G
+    L = 16
+    offsets, pls = oracle.grid_offsets(3, L, 2, 2, 16, 19, 4096, False)
+    B = 50003
+    x = ray_points(B // 50 + 1, 50, 7)[:B]
+    grad = (np.random.default_rng(8).normal(size=(L, B, 2)) * 0.05).astype(np.float16)
+    tg, tx, to = t(grad, dev), t(x, dev), t(offsets, dev)
+    one = G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False, out_dtype=torch.float16, out_scale=0.25)
+    seen = []
+    grouped = G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False, out_dtype=torch.float16, out_scale=0.25,
+                                      on_group=lambda out, r0, r1: seen.append((r0, r1)))
+    assert torch.equal(one, grouped)
+    assert len(seen) == G.LEVEL_GROUPS and seen[0][1] == int(offsets[-1]) and seen[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(seen[:-1], seen[1:]))                      # contiguous, descending
+    G.LEVEL_GROUPS, keep = 4, G.LEVEL_GROUPS
+    try:
+        seen4 = []
+        four = G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False, out_dtype=torch.float16, out_scale=0.25,
+                                       on_group=lambda out, r0, r1: seen4.append((r0, r1)))
+    finally:
+        G.LEVEL_GROUPS = keep
+    assert torch.equal(one, four) and len(seen4) == 4
+    assert seen4[-1][1] - seen4[-1][0] < 0.05 * int(offsets[-1])                        # with four groups the last (exposed) one is levels 0-3: 3 % of the rows
+    f32 = G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False, on_group=lambda *a: None)
+    assert torch.equal(f32, G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False))

@@ -24,7 +24,7 @@ inputs = ((xyzs + W.BOUND) / (2 * W.BOUND)).contiguous()
 L = 16
 grad = (torch.randn(L, M, 2, device=dev) * 1e-2).half()
 lib = hip.lib()
-rows, n = G.offsets_info(enc.offsets)
+rows, n, _ = G.offsets_info(enc.offsets)
 out = torch.empty(n, 2, device=dev)
 ws = hip.workspace(lib.ngp_grid_scatter_binned_workspace(M, L), dev)
 hip.check(lib.ngp_grid_scatter_binned(hip.ptr(grad), hip.ptr(inputs), hip.ptr(enc.offsets), hip.ptr(out), M, L, float(np.log2(enc.per_level_scale)), 16, rows, 0, 0, hip.F32, 1.0,
