@@ -13,6 +13,8 @@ Prints ONE JSON line (rank 0).  `roofline` prices the render kernel against HBM 
 (512 B per ray-sample); `cpu_baseline` is the CPU oracle (a port: the reference has no CPU path) on a bounded sample.
 """
 import argparse
+import contextlib
+import gc
 import importlib
 import json
 import os
@@ -43,6 +45,24 @@ SCATTER_BYTES_PER_POINT = 512          # 16 levels x 8 corners x 2 features x 2 
 
 FRAME_SOURCES = ("render_fused.hip", "ngp_field.h", "ngp_device.h", "ngp_march.h", "ngp_mlp.h", "ngp_sh.h", "ngp_camera.h", "Makefile")   # what k_render_frame_multi is built from
 TRAIN_SOURCES = ("gridencoder.hip", "ngp_device.h", "Makefile")                                                              # ... and k_grid_backward
+
+
+@contextlib.contextmanager
+def no_gc_pauses():
+    """Timed regions run with Python's cyclic garbage collector off.  A generation-2 collection of this process (torch + numpy: millions of tracked
+    objects) takes ~45 ms of HOST time; the HIP runtime lets the host run only a few launches ahead of the GPU, so the pause starves the queue and shows up
+    as ONE 45 ms step among 3.3 ms ones -- always at the same step of a run (measured: launch 76 of 100, 3.76 against 3.32 ms per step on average).  It is
+    host bookkeeping, not part of the path being measured; a long-running viewer would call gc.freeze() after set-up for the same reason."""
+    gc.collect()
+    gc.freeze()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+        gc.unfreeze()
 
 
 def sources_sha16(files=FRAME_SOURCES):
@@ -119,12 +139,13 @@ def bench_train(args, rank, world, dev, W, teacher):
 
     def timed_phase(first, count):
         ngp_hip.TIMERS = {}
-        sync_all()
-        t0 = time.perf_counter()
-        for k in range(count):
-            loss = step(first + k)
-        sync_all()
-        elapsed = time.perf_counter() - t0
+        with no_gc_pauses():
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(count):
+                loss = step(first + k)
+            sync_all()
+            elapsed = time.perf_counter() - t0
         scatter_ms, calls = ngp_hip.timer_ms("grid_encode_backward")
         ngp_hip.TIMERS = None
         return elapsed, float(loss), points_now(), scatter_ms, calls
@@ -237,15 +258,16 @@ def fitted_block(args, dev, W, teacher, rays, Wd):
         student.render_fused(*rays[k % len(rays)], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
     torch.cuda.synchronize()
     ev, stats = [], []
-    t0 = time.perf_counter()
-    for k in range(args.fit_frames):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = student.render_fused(*rays[k % len(rays)], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
-        b.record()
-        ev.append((a, b)); stats.append(out["stats"])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with no_gc_pauses():
+        t0 = time.perf_counter()
+        for k in range(args.fit_frames):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = student.render_fused(*rays[k % len(rays)], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
+            b.record()
+            ev.append((a, b)); stats.append(out["stats"])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     samples = int(torch.stack(stats)[:, 0].to(torch.int64).sum().item())
     kernel_s = 1e-3 * float(np.mean([a.elapsed_time(b) for a, b in ev]))
     per_launch = samples / args.fit_frames
@@ -411,15 +433,17 @@ def main():
 
     stats = []
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        out = frame(k)
-        ev[k][1].record()
-        if fused:
-            stats.append(out["stats"])
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    with no_gc_pauses():
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            out = frame(k)
+            ev[k][1].record()
+            if fused:
+                stats.append(out["stats"])
+        sync_all()
+        elapsed = time.perf_counter() - t0
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if fused:
@@ -479,6 +503,8 @@ def main():
             "traffic": None,
             "kernel": "k_render_frame_multi" if fused else "per-op loop (many kernels)",
             "avg_launch_ms": 1e3 * avg_kernel_s,
+            "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],
+            "slowest_launch_index": int(np.argmax(kernel_ms)),
             "algorithmic_bytes_per_sample": GATHER_BYTES_PER_SAMPLE,
             "mfma_tflops": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12,
             "mfma_frac": MLP_FLOPS_PER_SAMPLE * samples_per_launch / avg_kernel_s / 1e12 / MFMA_PEAK_TFLOPS,
@@ -525,15 +551,16 @@ def main():
         torch.cuda.synchronize()
         n_launch = max(args.steps // P_, 3)
         evm, stm = [], []
-        t1 = time.perf_counter()
-        for _ in range(n_launch):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            outm = ren.render_fused_cameras(poses_np, intr, H, Wd, dt_gamma=0, bg_color=1, max_steps=1024)
-            b.record()
-            evm.append((a, b)); stm.append(outm["stats"])
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
+        with no_gc_pauses():
+            t1 = time.perf_counter()
+            for _ in range(n_launch):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                outm = ren.render_fused_cameras(poses_np, intr, H, Wd, dt_gamma=0, bg_color=1, max_steps=1024)
+                b.record()
+                evm.append((a, b)); stm.append(outm["stats"])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
         smp = int(torch.stack(stm)[:, 0].to(torch.int64).sum().item())
         k_s = 1e-3 * float(np.mean([a.elapsed_time(b) for a, b in evm]))
         ach = GATHER_BYTES_PER_SAMPLE * (smp / n_launch) / k_s / 1e9
