@@ -784,6 +784,11 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
     const int start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));
     const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
     const bool merge = heads != ~0ull;                 // wave-uniform: false on the fine levels, where every sample sits in a cell of its own
+    // how this level is indexed (uniform over the workgroup): the strides of get_grid_index, and whether they all fit (dense) or the level is hashed
+    const uint32_t side = align_corners ? resolution : resolution + 1u;
+    const uint32_t s1 = side, s2 = side * side;
+    const bool idx_dense = (uint64_t)side * side * side <= (uint64_t)level_rows;           // every stride fits: x + y s1 + z s2 < rows, no modulo
+    const bool idx_pow2 = !idx_dense && gridtype == 0 && (level_rows & (level_rows - 1u)) == 0;   // hashed, 2^k rows: the modulo is a mask
     __syncthreads();                                   // s_hist is zero
 
     uint32_t e_val[8], e_key[8], e_rank[8];
@@ -805,7 +810,13 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
             }
         }
         const bool send = tail && valid && !(v0 == 0.0f && v1 == 0.0f);
-        const uint32_t row = ge_index<D>(gridtype, align_corners, level_rows, resolution, pl);
+        // get_grid_index (gridencoder.cu:54-72) without its `% hashmap_size` where that is the identity or a mask -- a 32-bit division by a
+        // run-time divisor is ~20 VALU instructions, eight times per lane, in a kernel that is VALU-bound (profiles/r15_train): a level is either
+        // dense (its last stride fits: the index is below the row count by construction) or hashed with 2^k rows (mask); wave-uniform choice
+        uint32_t row;
+        if (idx_dense) row = pl[0] + pl[1] * s1 + pl[2] * s2;
+        else if (idx_pow2) row = (pl[0] ^ (pl[1] * 2654435761u) ^ (pl[2] * 805459861u)) & (level_rows - 1u);
+        else row = ge_index<D>(gridtype, align_corners, level_rows, resolution, pl);
         h2 hv;
         hv.x = ngp_f2h(v0);
         hv.y = ngp_f2h(v1);
