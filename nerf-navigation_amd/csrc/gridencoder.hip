@@ -777,13 +777,21 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
 
     // runs of consecutive lanes in the same cell (consecutive samples of a ray): summed across the run, the last lane emits
     const int lane = (int)(tid & 63u);
-    bool same = valid && lane > 0 && __shfl_up((int)valid, 1, 64) != 0;
+    // (wave_shr:1 = the value of the lane below, on the VALU: no ds_bpermute)
+    #define GS_BELOW(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x138, 0xF, 0xF, false)
+    bool same = valid && lane > 0 && GS_BELOW(valid) != 0;
     #pragma unroll
-    for (uint32_t d = 0; d < D; d++) same = (__shfl_up(pg[d], 1, 64) == pg[d]) && same;
+    for (uint32_t d = 0; d < D; d++) same = ((uint32_t)GS_BELOW(pg[d]) == pg[d]) && same;
+    #undef GS_BELOW
     const unsigned long long heads = __ballot(!same);
     const int start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));
     const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
     const bool merge = heads != ~0ull;                 // wave-uniform: false on the fine levels, where every sample sits in a cell of its own
+    float take[6];                                     // see the run sums below
+    #pragma unroll
+    for (int k = 0; k < 4; k++) take[k] = (lane - (1 << k) >= start) ? 1.0f : 0.0f;        // row_shr:2^k (a source outside the row reads 0)
+    take[4] = (start < (lane & ~15)) ? 1.0f : 0.0f;                                        // the run reaches into the row below
+    take[5] = (lane >= 32 && start < 32) ? 1.0f : 0.0f;                                    // ... and into the lower half of the wave
     // how this level is indexed (uniform over the workgroup): the strides of get_grid_index, and whether they all fit (dense) or the level is hashed
     const uint32_t side = align_corners ? resolution : resolution + 1u;
     const uint32_t s1 = side, s2 = side * side;
@@ -803,11 +811,19 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
         }
         float v0 = wi * g0, v1 = wi * g1;
         if (merge) {
-            #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float o0 = __shfl_up(v0, off, 64), o1 = __shfl_up(v1, off, 64);
-                if (lane - off >= start) { v0 += o0; v1 += o1; }
-            }
+            // segmented inclusive sum over the run, on the VALU alone (DPP): four steps inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the carry
+            // from the row below (row_bcast:15 into rows 1 and 3) and from the lower half (row_bcast:31 into rows 2 and 3).  Whether a lane may take a
+            // step's value is the same for all eight corners: 1.0 / 0.0 multipliers computed once (take[]), a step is one fused multiply-add per value
+            // (fma(o, 1, v) = o + v exactly, fma(o, 0, v) = v; an inf / NaN contribution -- a loss-scale overflow -- may spread to a neighbouring run
+            // through 0 * inf: the step is skipped either way).  The 96 ds_bpermute of a shuffle-based scan kept the CU's LDS pipe busy for ~11 us per
+            // workgroup: THAT, not the VALU, bounded the kernel on the levels where runs exist.
+            #define GS_DPP(v, ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rows, 0xF, true))
+            #define GS_STEP(ctrl, rows, k) { const float o0 = GS_DPP(v0, ctrl, rows), o1 = GS_DPP(v1, ctrl, rows); \
+                                             v0 = __builtin_fmaf(o0, take[k], v0); v1 = __builtin_fmaf(o1, take[k], v1); }
+            GS_STEP(0x111, 0xF, 0) GS_STEP(0x112, 0xF, 1) GS_STEP(0x114, 0xF, 2) GS_STEP(0x118, 0xF, 3)
+            GS_STEP(0x142, 0xA, 4) GS_STEP(0x143, 0xC, 5)
+            #undef GS_STEP
+            #undef GS_DPP
         }
         const bool send = tail && valid && !(v0 == 0.0f && v1 == 0.0f);
         // get_grid_index (gridencoder.cu:54-72) without its `% hashmap_size` where that is the identity or a mask -- a 32-bit division by a
