@@ -705,14 +705,19 @@ extern "C" int ngp_grid_encode_backward_inputs(const void* grad, const float* in
 // =====================================================================================================================================
 static constexpr uint32_t GS_CHUNK = 1024;            // samples per region = threads per k_gs_bin workgroup
 static constexpr uint32_t GS_REGION = GS_CHUNK * 8;   // entries a region can hold (every corner of every sample)
-static constexpr uint32_t GS_MAX_SLICES = 64;         // slices per level (directory rows: GS_MAX_SLICES + 1)
+static constexpr uint32_t GS_MAX_SLICES = 128;        // slices per level (directory rows: GS_MAX_SLICES + 1)
 static constexpr uint32_t GS_SLICE_ROWS = 8192;       // rows per slice of a large level (2 x 64-bit fixed-point accumulators per row = 128 KiB of LDS)
 static constexpr uint32_t GS_PASS_SAMPLES = 1u << 22; // samples per pass: one pass for any 4,096-ray x 1,024-step training batch (workspace <= 3.2 GB;
                                                        // more samples run in further passes that add into the output)
 
-// rows per slice as a shift: levels of up to 2^18 rows are cut into 4,096-row slices so that the few, heavily hit rows of the coarse
-// levels spread over several workgroups; larger (hashed) levels into 8,192-row slices so that a region's piece per slice stays long
-__device__ __forceinline__ uint32_t gs_shift(uint32_t level_rows) { return level_rows > (1u << 18) ? 13u : 12u; }
+// rows per slice as a shift: a level is cut into about 64 slices -- 8,192 rows for a hashed level of 2^19 rows (the most the LDS holds: 128 KiB of accumulators),
+// down to 512 rows for the coarsest levels.  The few rows of a coarse level collect as many entries as a whole fine level's slice does, and a slice is summed by
+// ONE workgroup: with 4,096-row slices level 0 was a single slice of 1.26 M entries and the launch waited for it (1.22 ms on 4.19 M points, see HISTORY).
+__device__ __forceinline__ uint32_t gs_shift(uint32_t level_rows) {
+    const uint32_t per = (level_rows + 63u) >> 6;                       // rows per slice for 64 slices
+    uint32_t sh = per <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(per - 1u);   // ceil(log2(per))
+    return sh < 9u ? 9u : (sh > 13u ? 13u : sh);
+}
 
 // A half as a 64-bit fixed-point number in units of 2^-24 (the smallest half subnormal): EXACT for every finite half (|q| < 2^40), so
 // the sum of up to 2^22 entries is exact in 64 bits and does not depend on the order of the adds -- the LDS adds are integer adds
@@ -777,12 +782,10 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
 
     // runs of consecutive lanes in the same cell (consecutive samples of a ray): summed across the run, the last lane emits
     const int lane = (int)(tid & 63u);
-    // (wave_shr:1 = the value of the lane below, on the VALU: no ds_bpermute)
-    #define GS_BELOW(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0x138, 0xF, 0xF, false)
-    bool same = valid && lane > 0 && GS_BELOW(valid) != 0;
+    // (four ds_bpermute per wave; DPP wave_shr:1 does not carry across the rows of 16 lanes on this chip: runs were cut at lanes 16 / 32 / 48)
+    bool same = valid && lane > 0 && __shfl_up((int)valid, 1, 64) != 0;
     #pragma unroll
-    for (uint32_t d = 0; d < D; d++) same = ((uint32_t)GS_BELOW(pg[d]) == pg[d]) && same;
-    #undef GS_BELOW
+    for (uint32_t d = 0; d < D; d++) same = (__shfl_up(pg[d], 1, 64) == pg[d]) && same;
     const unsigned long long heads = __ballot(!same);
     const int start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));
     const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
@@ -838,21 +841,22 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
         hv.y = ngp_f2h(v1);
         e_val[idx] = __builtin_bit_cast(uint32_t, hv);
         uint32_t slice = row >> shift;
-        if (slice >= GS_MAX_SLICES) slice = GS_MAX_SLICES - 1;                              // (never for levels of <= 2^20 rows; the host checks)
+        if (slice >= GS_MAX_SLICES) slice = GS_MAX_SLICES - 1;                              // (never for levels of <= 2^19 rows; the host checks)
         e_key[idx] = send ? ((slice << 16) | (row - (slice << shift))) : 0xFFFFFFFFu;
         e_rank[idx] = send ? atomicAdd(&s_hist[slice], 1u) : 0u;                            // ds_add_rtn_u32: the entry's rank inside its slice
     }
     __syncthreads();
-    if (tid < 64) {                                    // exclusive scan of the 64 slice counts by one wave
-        const uint32_t c = s_hist[tid];
-        uint32_t incl = c;
+    if (tid < 64) {                                    // exclusive scan of the 128 slice counts by one wave (two per lane)
+        const uint32_t c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
+        uint32_t incl = c0 + c1;
         #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, 64);
             if ((int)tid >= off) incl += o;
         }
-        s_hist[tid] = incl - c;
-        if (tid == 63) s_hist[64] = incl;
+        s_hist[2 * tid] = incl - c0 - c1;
+        s_hist[2 * tid + 1] = incl - c1;
+        if (tid == 63) s_hist[GS_MAX_SLICES] = incl;
     }
     __syncthreads();
     #pragma unroll
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
         }
     }
     __syncthreads();
-    const uint32_t total = s_hist[64];
+    const uint32_t total = s_hist[GS_MAX_SLICES];
     const size_t region = ((size_t)level * nchunks + chunk) * GS_REGION;
     for (uint32_t k = tid; k < total; k += GS_CHUNK) g_vals[region + k] = s_vals[k];
     uint32_t* rows32 = reinterpret_cast<uint32_t*>(g_rows + region);
@@ -937,22 +941,26 @@ __global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restri
             off = 0; cnt = 0;
             if (it + 16 < n_it) { const uint32_t rn = (it + 16) * 4 + sub; if (rn < nchunks) { off = dir0[rn]; cnt = (uint32_t)dir1[rn] - off; } }
             const size_t base = ((size_t)level * nchunks + r) * GS_REGION + o;
-            for (uint32_t k = l16; k < c; k += 32) {
-                const bool two = k + 16 < c;
-                const uint32_t va = g_vals[base + k], ra = g_rows[base + k];
-                const uint32_t vb = two ? g_vals[base + k + 16] : 0u, rb = two ? g_rows[base + k + 16] : 0xFFFFu;
-                long long q0, q1, q2, q3;
-                const bool fa = gs_half_to_fixed(va & 0xFFFFu, q0), fb = gs_half_to_fixed(va >> 16, q1);
-                const bool fc = gs_half_to_fixed(vb & 0xFFFFu, q2), fd = gs_half_to_fixed(vb >> 16, q3);
-                if (!(fa && fb && fc && fd)) s_poison = 1u;
-                else {
-                    if (ra < nrows) {
-                        atomicAdd(&s_acc[2 * ra], (unsigned long long)q0);                  // ds_add_u64, no return
-                        atomicAdd(&s_acc[2 * ra + 1], (unsigned long long)q1);
-                    }
-                    if (rb < nrows) {
-                        atomicAdd(&s_acc[2 * rb], (unsigned long long)q2);
-                        atomicAdd(&s_acc[2 * rb + 1], (unsigned long long)q3);
+            // GS_PER_LANE entries per lane per trip, all their loads issued before the first add: the kernel is a chain of load -> LDS round trips, so
+            // what counts is bytes in flight (2 per lane: 1.11 ms, 4: 0.93, 8: 0.88 on 4.19 M points; issuing the next iteration's first trip before
+            // this one's adds on top of that: 0.90)
+            constexpr uint32_t GS_PER_LANE = 8;
+            for (uint32_t k = l16; k < c; k += 16 * GS_PER_LANE) {
+                uint32_t v[GS_PER_LANE], rw[GS_PER_LANE];
+                #pragma unroll
+                for (uint32_t j = 0; j < GS_PER_LANE; j++) {
+                    const bool in = k + 16 * j < c;
+                    v[j] = in ? g_vals[base + k + 16 * j] : 0u;
+                    rw[j] = in ? (uint32_t)g_rows[base + k + 16 * j] : 0xFFFFu;
+                }
+                #pragma unroll
+                for (uint32_t j = 0; j < GS_PER_LANE; j++) {
+                    long long q0, q1;
+                    const bool f0 = gs_half_to_fixed(v[j] & 0xFFFFu, q0), f1 = gs_half_to_fixed(v[j] >> 16, q1);
+                    if (!(f0 && f1)) s_poison = 1u;
+                    else if (rw[j] < nrows) {
+                        atomicAdd(&s_acc[2 * rw[j]], (unsigned long long)q0);               // ds_add_u64, no return
+                        atomicAdd(&s_acc[2 * rw[j] + 1], (unsigned long long)q1);
                     }
                 }
             }
@@ -979,7 +987,7 @@ static int gs_run(const char* who, const void* grad, const float* inputs, const 
     NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "%s: L must be in 1..32", who);
     NGP_REQUIRE(level_lo < level_hi && level_hi <= L, "%s: bad level range", who);
     NGP_REQUIRE(out_dtype == NGP_F32 || out_dtype == NGP_F16, "%s: out_dtype must be f32 or f16", who);
-    NGP_REQUIRE(max_level_rows >= 1 && max_level_rows <= GS_MAX_SLICES * GS_SLICE_ROWS,
+    NGP_REQUIRE(max_level_rows >= 1 && max_level_rows <= 64u * GS_SLICE_ROWS,
                 "%s: a level may have at most 2^19 rows (use grid_encode_backward for larger tables)", who);
     const bool split = !(do_bin && do_sum && level_lo == 0 && level_hi == L);
     NGP_REQUIRE(!split || B <= GS_PASS_SAMPLES, "%s: binning and summing in separate calls needs B <= 2^22 samples (one pass)", who);

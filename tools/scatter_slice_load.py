@@ -30,9 +30,9 @@ ws = hip.workspace(lib.ngp_grid_scatter_binned_workspace(M, L), dev)
 hip.check(lib.ngp_grid_scatter_binned(hip.ptr(grad), hip.ptr(inputs), hip.ptr(enc.offsets), hip.ptr(out), M, L, float(np.log2(enc.per_level_scale)), 16, rows, 0, 0, hip.F32, 1.0,
                                       hip.ptr(ws), ws.numel(), hip.stream()))
 torch.cuda.synchronize()
-nchunks = (min(M, 1 << 21) + 1023) // 1024
-dirs_ = ws[256:256 + L * 65 * nchunks * 2].view(torch.int16).cpu().numpy().view(np.uint16).reshape(L, 65, nchunks).astype(np.int64)
-per = (dirs_[:, 1:, :] - dirs_[:, :-1, :]).sum(axis=2)          # [L, 64]
+nchunks = (min(M, 1 << 22) + 1023) // 1024
+dirs_ = ws[256:256 + L * 129 * nchunks * 2].view(torch.int16).cpu().numpy().view(np.uint16).reshape(L, 129, nchunks).astype(np.int64)
+per = (dirs_[:, 1:, :] - dirs_[:, :-1, :]).sum(axis=2)          # [L, 128]
 print("points", M, "regions", nchunks, "entries", int(per.sum()), "per point", per.sum() / M)
 for l in range(L):
     nz = per[l][per[l] > 0]
