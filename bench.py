@@ -137,6 +137,8 @@ def bench_train(args, rank, world, dev, W, teacher):
         n = min(16, student.local_step)
         return float(student.step_counter[:n, 0].float().mean().item()) if n else float(student.mean_count)
 
+    host_ms = [None]                                                       # ms per step the host needed to queue the last timed phase
+
     def timed_phase(first, count):
         ngp_hip.TIMERS = {}
         with no_gc_pauses():
@@ -144,10 +146,12 @@ def bench_train(args, rank, world, dev, W, teacher):
             t0 = time.perf_counter()
             for k in range(count):
                 loss = step(first + k)
+            queued = time.perf_counter() - t0                                  # the host has queued every launch; the GPU may still be running
             sync_all()
             elapsed = time.perf_counter() - t0
         scatter_ms, calls = ngp_hip.timer_ms("grid_encode_backward")
         ngp_hip.TIMERS = None
+        host_ms[0] = queued / count * 1e3
         return elapsed, float(loss), points_now(), scatter_ms, calls
 
     k0 = 0
@@ -193,6 +197,7 @@ def bench_train(args, rank, world, dev, W, teacher):
             # between the end of the backward and the gradients being ready (events on the compute stream); zero / null without a process group
             "allreduce_bytes": tr.exchange.stats["allreduce_bytes"], "exposed_collective_ms": tr.exchange.exposed_ms(),
             "weight_ema": {"decay": 0.95, "updates": tr.ema.num_updates, "every_steps": len(pool)},
+            "host_queue_ms_per_step": host_ms[0],
             "roofline": roof(points, scatter_ms),
             "warmup_phase": {"ms_per_step": 1e3 * warm[0] / args.steps, "points_per_step": warm[2], "loss": warm[1],
                              "roofline": roof(warm[2], warm[3], profiled_phase=True)}}))

@@ -83,6 +83,13 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                          int32_t* rays, int32_t* counter, uint32_t perturb,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for xyzs / dirs / deltas that were NOT pre-zeroed (torch.empty): the call zeroes the slots no ray fills itself (they form one tail). */
+int ngp_march_rays_train_filled(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                int32_t* rays, int32_t* counter, uint32_t perturb,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* Validation switch, process-wide, default 1: with dt_gamma == 0 the count pass of ngp_march_rays_train marches one WAVE per ray (64 lattice
  * points per step, csrc/raymarching.hip: k_march_train_count_wave) instead of one lane per ray.  Same samples, counts and order either way;
  * returns the previous setting. */
@@ -217,6 +224,59 @@ int ngp_grid_scatter_binned_phase(int phase, const void* grad, const float* inpu
                                   uint32_t B, uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H, uint32_t max_level_rows,
                                   uint32_t gridtype, int align_corners, int out_dtype, float out_scale, void* workspace, size_t workspace_bytes,
                                   void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* optimiser step of the training loop                                       */
+/* (reference: main_nerf.py:126 torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15); nerf/utils.py:329 GradScaler,       */
+/*  :789-791 scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update() -- torch library code there, three native launches here) */
+/* ------------------------------------------------------------------------ */
+
+#define NGP_ADAM_MAX_TENSORS 16
+/* words of the 32-word device state buffer a caller may read or initialise (float32 unless noted) */
+#define NGP_ADAM_STATE_WORDS 32
+#define NGP_ADAM_STATE_SCALE 0           /* GradScaler's scale; initialise (torch: 65536) */
+#define NGP_ADAM_STATE_GROWTH_TRACKER 1  /* int32: unskipped steps since the scale last changed */
+#define NGP_ADAM_STATE_STEP 2            /* int32: Adam's step count t (skipped steps do not count) */
+#define NGP_ADAM_STATE_FOUND_INF 4       /* 1.0 if the last call found a non-finite gradient and skipped the update, else 0.0 */
+
+typedef struct {
+    void* param;          /* float32 [n], updated in place */
+    const void* grad;     /* float32 [n], still multiplied by the loss scale; read only */
+    void* exp_avg;        /* float32 [n] */
+    void* exp_avg_sq;     /* float32 [n] */
+    void* half_copy;      /* float16 [n] or NULL: receives the updated parameters rounded to half (what an autocast forward reads) */
+    uint64_t n;
+    double lr;            /* this tensor's learning rate for this step (param_group['lr'] after the scheduler) */
+} ngp_adam_tensor_t;
+
+typedef struct {
+    double beta1, beta2, eps;
+    double growth_factor, backoff_factor;   /* GradScaler: 2.0, 0.5 */
+    int32_t growth_interval;                /* GradScaler: 2000 */
+    int32_t scaler_enabled;                 /* 0: no loss scaling -- gradients are used as they are, never checked, the scale words are not touched */
+} ngp_adam_hyper_t;
+
+/* One optimiser step for `count` <= NGP_ADAM_MAX_TENSORS tensors: non-finite check of all gradients, GradScaler's skip decision and scale update,
+ * Adam (weight_decay 0, amsgrad off) with the arithmetic of torch.optim.Adam (csrc/adam.hip spells it out).  `tensors` and `hyper` are host memory, read
+ * before the call returns; `state` is device memory (NGP_ADAM_STATE_WORDS words, zero-filled + the scale by the caller before the first step), and nothing
+ * is read back: the host never waits. */
+int ngp_adam_step(const ngp_adam_tensor_t* tensors, uint32_t count, const ngp_adam_hyper_t* hyper, float* state, void* stream);
+
+/* Between the compositor and the loss of a training step (csrc/train_head.hip; torch elementwise ops in the reference, ~20 launches under autograd).
+ * mix: nerf/renderer.py:318-319  out_image = image + (1 - weights_sum)[:, None] * bg_color;  out_depth = clamp(depth - nears, min=0) / (fars - nears)
+ * (out_depth may be NULL).  bg_rows: 0 = bg_value for every channel, 1 = bg[3], N = bg[N,3].  backward: grad_weights_sum = -(grad_out_image . bg); the
+ * gradient of `image` is grad_out_image itself; the compositor ignores the gradient of depth (raymarching.py:270), so none is formed. */
+int ngp_train_mix_forward(const float* weights_sum, const float* depth, const float* image, const float* nears, const float* fars,
+                          const float* bg, uint32_t bg_rows, float bg_value, uint32_t N, float* out_image, float* out_depth, void* stream);
+int ngp_train_mix_backward(const float* grad_out_image, const float* bg, uint32_t bg_rows, float bg_value, uint32_t N, float* grad_weights_sum, void* stream);
+/* mse head: nerf/utils.py:450,480 loss = mean((pred - target)^2), :789 scaler.scale(loss).  loss[0] = the mean, loss[1] = the mean * scale[0] (scale may be
+ * NULL: loss[1] = loss[0]); grad_unit [numel] = 2 / numel * (pred - target), the gradient for a unit incoming one.  workspace: ngp_mse_head_workspace() bytes,
+ * zero-filled once by the caller, one per stream.  backward: grad_pred = grad_unit * (grad_loss[0] + grad_scaled[0] * scale[0]); either may be NULL. */
+size_t ngp_mse_head_workspace(void);
+int ngp_mse_head_forward(const float* pred, const float* target, uint32_t numel, const float* scale, float* loss, float* grad_unit,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int ngp_mse_head_backward(const float* grad_unit, const float* grad_loss, const float* grad_scaled, const float* scale, uint32_t numel,
+                          float* grad_pred, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* _shencoder  (reference: shencoder/src/shencoder.h:10,13)                  */

@@ -420,14 +420,25 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restr
     if (threadIdx.x == 0) {
         bases[0] = start;
         bases[1] = (uint32_t)counter[1];
+        bases[2] = carry;                            // first slot no ray of this call fills; k_march_train_write lowers it to the first dropped ray's
         counter[0] = (int)carry;
         counter[1] = (int)((uint32_t)counter[1] + N);
     }
 }
 
+// The slots [bases[2], M) that no ray of the call fills, zeroed like the torch.zeros buffers the reference's wrapper hands in (raymarching.py:205-208;
+// a zero delta marks a sample that does not exist, raymarching.cu:548).  Ray slots are prefix sums, so from the first ray that does not fit on nothing
+// is written: one contiguous tail.
+__global__ __launch_bounds__(RM_BLOCK) void k_march_train_zero_tail(const uint32_t* __restrict__ bases, uint32_t M, float* __restrict__ xyzs,
+                                                                    float* __restrict__ dirs, float* __restrict__ deltas) {
+    const uint32_t lo = bases[2] < M ? bases[2] : M;
+    for (uint64_t i = 3ull * lo + blockIdx.x * RM_BLOCK + threadIdx.x; i < 3ull * M; i += (uint64_t)gridDim.x * RM_BLOCK) { xyzs[i] = 0.0f; dirs[i] = 0.0f; }
+    for (uint64_t i = 2ull * lo + blockIdx.x * RM_BLOCK + threadIdx.x; i < 2ull * M; i += (uint64_t)gridDim.x * RM_BLOCK) deltas[i] = 0.0f;
+}
+
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a, int* __restrict__ rays,
                                                                 const uint32_t* __restrict__ block_sums,
-                                                                const uint32_t* __restrict__ bases,
+                                                                uint32_t* bases /* [0], [1] read; [2] lowered by the first ray that does not fit */,
                                                                 float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                 float* __restrict__ deltas, int offsets_only) {
     __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
@@ -442,6 +453,8 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a
     const uint32_t point_index = block_sums[blockIdx.x] + inc - num_steps;
     rays[3ull * slot] = (int)n;
     rays[3ull * slot + 1] = (int)point_index;
+    // the first ray whose samples do not fit (there is at most one with point_index < M <= point_index + num_steps): the unfilled tail starts at its slot
+    if (num_steps != 0 && point_index < a.M && point_index + num_steps >= a.M) bases[2] = point_index;
     if (offsets_only) return;                        // k_march_train_fill writes the samples from the recorded parameters
     if (num_steps == 0) return;
     if (point_index + num_steps >= a.M) return;      // dropped ray (reference :420)
@@ -522,12 +535,20 @@ extern "C" size_t ngp_march_rays_train_workspace_full(uint32_t N, uint32_t max_s
     return ngp_march_rays_train_workspace(N) + sizeof(float) * (size_t)N * max_steps;
 }
 
-extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
-                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
-                                    int32_t* rays, int32_t* counter, uint32_t perturb,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    if (N == 0) return NGP_OK;
+static int rm_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                               uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                               const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                               int32_t* rays, int32_t* counter, uint32_t perturb,
+                               void* workspace, size_t workspace_bytes, void* stream, bool zero_tail) {
+    if (N == 0) {
+        if (zero_tail && M) {
+            NGP_REQUIRE(xyzs && dirs && deltas, "march_rays_train: null pointer");
+            const hipError_t e0 = hipMemsetAsync(xyzs, 0, 12ull * M, (hipStream_t)stream), e1 = hipMemsetAsync(dirs, 0, 12ull * M, (hipStream_t)stream),
+                             e2 = hipMemsetAsync(deltas, 0, 8ull * M, (hipStream_t)stream);
+            if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) return ngp_fail(NGP_ELAUNCH, "march_rays_train: hipMemsetAsync failed");
+        }
+        return NGP_OK;
+    }
     NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter, "march_rays_train: null pointer");
     NGP_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 1024 && max_steps >= 1, "march_rays_train: bad C/H/max_steps");
     NGP_REQUIRE(workspace && workspace_bytes >= ngp_march_rays_train_workspace(N), "march_rays_train: workspace too small");
@@ -553,8 +574,31 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
     hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
     hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas, tbuf ? 1 : 0);
     if (tbuf) hipLaunchKernelGGL(k_march_train_fill, dim3(N), dim3(RM_RAY_BLOCK), 0, s, a, rays, bases, tbuf, xyzs, dirs, deltas);
+    if (zero_tail && M) {
+        const uint32_t zb = ngp_div_up(3ull * M, RM_BLOCK * 8ull);
+        hipLaunchKernelGGL(k_march_train_zero_tail, dim3(zb < 2048u ? (zb ? zb : 1u) : 2048u), dim3(RM_BLOCK), 0, s, bases, M, xyzs, dirs, deltas);
+    }
     NGP_CHECK_LAUNCH("march_rays_train");
     return NGP_OK;
+}
+
+extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                    int32_t* rays, int32_t* counter, uint32_t perturb,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return rm_march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb, workspace,
+                               workspace_bytes, stream, false);
+}
+
+// The same, for buffers that were NOT zeroed: the slots no ray fills are zeroed by the call (one small launch instead of three whole-buffer fills).
+extern "C" int ngp_march_rays_train_filled(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                           const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                           int32_t* rays, int32_t* counter, uint32_t perturb,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    return rm_march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb, workspace,
+                               workspace_bytes, stream, true);
 }
 
 // ---------------------------------------------------------------------------

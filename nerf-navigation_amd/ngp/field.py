@@ -145,15 +145,26 @@ class _ParamEpoch:
         for the first frozen-model call after the step (ADVICE r2);
       * at every forward that is differentiated with respect to the parameters (kept: it costs nothing and covers a caller that swaps
         parameter storage between steps).
-    `mark_updated()` is for callers that write parameters by other means (load_state_dict does bump `_version`; `p.data = ...` does not)."""
+    `mark_updated()` is for callers that write parameters by other means (load_state_dict does bump `_version`; `p.data = ...` does not).
+
+    An optimiser that REFRESHES the half copies itself (ngp/optim.py NativeAdam writes them in its update launch) says so with
+    `mirrors_are_current()` (NGPFieldFF): the copies then stay valid through the next training forward, which would otherwise convert
+    the 12.7 M-entry table again on every step.  `_foreign_writes` counts the `mark_updated()` calls, the writes this class cannot see."""
     _param_epoch = 0
+    _foreign_writes = 0
+    _mirror_ok = False
 
     def _training_forward(self):
-        if torch.is_grad_enabled() and self.encoder.embeddings.requires_grad:
+        if torch.is_grad_enabled() and self.encoder.embeddings.requires_grad and not self._mirror_ok:
             self._param_epoch += 1
 
     def mark_updated(self):
         self._param_epoch += 1
+        self._foreign_writes += 1
+        self._mirror_ok = False
+        emb = getattr(getattr(self, "encoder", None), "embeddings", None)
+        if emb is not None:
+            emb._ngp_half = None                     # the op-by-op encoder's own half copy (gridencoder/grid.py) is keyed on `_version` alone
 
     def _watch_parameters(self):
         """call at the end of __init__: every parameter's gradient accumulation advances the epoch (the hook holds the module weakly)"""
@@ -164,6 +175,7 @@ class _ParamEpoch:
             me = ref()
             if me is not None:
                 me._param_epoch += 1
+                me._mirror_ok = False
         for p in self.parameters():
             p.register_post_accumulate_grad_hook(bump)
 
@@ -289,13 +301,12 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         self._check_fused_shape()
         scale = float(self.density_scale if density_scale is None else density_scale)
         emb_p = self.encoder.embeddings
-        key = (self._param_epoch, emb_p._version, self.sigma_net.weights._version, self.color_net.weights._version, emb_p.data_ptr(), str(emb_p.device),
-               self.sigma_net.weights.data_ptr(), self.color_net.weights.data_ptr(), self.encoder.offsets.data_ptr(), float(self.bound))
+        key = self._fused_key()
         if self._fused is None or self._fused["key"] != key:
             emb = emb_p.detach().to(torch.half).contiguous()
             ws = self.sigma_net.weights.detach().to(torch.half).contiguous()
             wc = self.color_net.weights.detach().to(torch.half).contiguous()
-            self._fused = {"key": key, "tensors": (emb, ws, wc), "structs": {}}
+            self._fused = {"key": key, "tensors": (emb, ws, wc), "structs": {}, "storage": self._storage_key()}
         st = self._fused["structs"]
         if scale not in st:
             emb, ws, wc = self._fused["tensors"]
@@ -303,6 +314,37 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
                                          self.encoder.num_levels, self.encoder.base_resolution,
                                          float(np.log2(self.encoder.per_level_scale)), float(self.bound), scale)
         return st[scale]
+
+    def _storage_key(self):
+        """what identifies the parameter VALUES as far as torch and `mark_updated()` can tell (gradient accumulation does not change them)"""
+        emb_p, ws, wc = self.encoder.embeddings, self.sigma_net.weights, self.color_net.weights
+        return (self._foreign_writes, emb_p._version, ws._version, wc._version, emb_p.data_ptr(), ws.data_ptr(), wc.data_ptr(), str(emb_p.device))
+
+    def _fused_key(self):
+        return (self._param_epoch,) + self._storage_key() + (self.encoder.offsets.data_ptr(), float(self.bound))
+
+    @torch.no_grad()
+    def half_mirrors(self):
+        """{parameter: the float16 copy the fused kernels read} for an optimiser that writes the copies itself (ngp/optim.py NativeAdam.half_mirrors).
+        The buffers of the last forward are handed out as they are when the parameters have not been written since (a backward in between only
+        advanced the epoch); otherwise they are rebuilt from the parameters first, so that a skipped update leaves valid copies behind."""
+        self._check_fused_shape()
+        if self._fused is None or self._fused.get("storage") != self._storage_key():
+            self._fused = None
+            self.fused_state()
+        emb, ws, wc = self._fused["tensors"]
+        return {self.encoder.embeddings: emb, self.sigma_net.weights: ws, self.color_net.weights: wc}
+
+    def mirrors_are_current(self):
+        """the optimiser has just updated the parameters AND the buffers `half_mirrors()` handed out (or skipped both): keep them for the next forward"""
+        emb_p = self.encoder.embeddings
+        if self._fused is not None:
+            self._fused["key"] = self._fused_key()
+            self._fused["storage"] = self._storage_key()
+            self._mirror_ok = True
+            emb_p._ngp_half = (emb_p._version, emb_p.data_ptr(), self._fused["tensors"][0])      # the op-by-op encoder reads the same copy
+        else:
+            emb_p._ngp_half = None
 
     @torch.no_grad()
     def forward_fused(self, x, d, density_scale=None):

@@ -40,6 +40,56 @@ def sample_pdf(bins, weights, n_samples, det=False, generator=None):
     return b_lo + (u - c_lo) / span * (b_hi - b_lo)
 
 
+class _mix_background(torch.autograd.Function):
+    """nerf/renderer.py:318-319 (and :370-371 after the inference loop) in one launch each way (csrc/train_head.hip):
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color;   depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+    bg: a Python number, or a float32 tensor [3] / [N,3] that needs no gradient.  Backward: grad_weights_sum = -(g . bg), the gradient of `image` is g
+    itself; `depth`'s is dropped, as the compositor drops it (raymarching/raymarching.py:270: grad_depth is never used)."""
+
+    @staticmethod
+    def forward(ctx, weights_sum, depth, image, nears, fars, bg):
+        N = weights_sum.shape[0]
+        ws, dp, im = weights_sum.contiguous(), depth.contiguous(), image.contiguous()
+        if isinstance(bg, torch.Tensor):
+            bg_t = bg.to(torch.float32).contiguous()
+            bg_rows, bg_value = (1 if bg_t.numel() == 3 else N), 0.0
+        else:
+            bg_t, bg_rows, bg_value = None, 0, float(bg)
+        out_image = torch.empty(N, 3, dtype=torch.float32, device=ws.device)
+        out_depth = torch.empty(N, dtype=torch.float32, device=ws.device)
+        _hip.check(_hip.lib().ngp_train_mix_forward(_hip.ptr(ws), _hip.ptr(dp), _hip.ptr(im), _hip.ptr(nears.contiguous()), _hip.ptr(fars.contiguous()),
+                                                    _hip.ptr(bg_t), bg_rows, bg_value, N, _hip.ptr(out_image), _hip.ptr(out_depth), _hip.stream()),
+                   "train_mix_forward")
+        ctx.bg = (bg_t, bg_rows, bg_value, N)
+        ctx.mark_non_differentiable(out_depth)
+        return out_image, out_depth
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth):
+        bg_t, bg_rows, bg_value, N = ctx.bg
+        g_image = g_image.contiguous().float()
+        g_ws = torch.empty(N, dtype=torch.float32, device=g_image.device)
+        _hip.check(_hip.lib().ngp_train_mix_backward(_hip.ptr(g_image), _hip.ptr(bg_t), bg_rows, bg_value, N, _hip.ptr(g_ws), _hip.stream()),
+                   "train_mix_backward")
+        return g_ws, None, g_image, None, None, None
+
+
+def mix_background(weights_sum, depth, image, nears, fars, bg_color):
+    """the two lines that end both branches of run_cuda; one native launch when the operands allow it, the reference's torch ops otherwise (a background
+    MODEL's colours need their own gradient; CPU tensors)"""
+    native = (weights_sum.is_cuda and weights_sum.dtype == torch.float32 and image.dtype == torch.float32 and depth.dtype == torch.float32
+              and weights_sum.dim() == 1 and image.shape == (weights_sum.shape[0], 3))
+    if isinstance(bg_color, torch.Tensor):
+        native = native and not bg_color.requires_grad and bg_color.device == weights_sum.device and tuple(bg_color.shape) in ((3,), (weights_sum.shape[0], 3))
+    else:
+        native = native and isinstance(bg_color, (int, float))
+    if native:
+        return _mix_background.apply(weights_sum, depth, image, nears, fars, bg_color)
+    image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+    depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+    return image, depth
+
+
 class NGPRenderer(nn.Module):
     def __init__(self, field, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.01, grid_size=128, bg_radius=-1):
         super().__init__()
@@ -121,10 +171,10 @@ class NGPRenderer(nn.Module):
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb,
                                                                     128, force_all_rays, dt_gamma, max_steps)
             sigmas, rgbs = self(xyzs, dirs)
-            sigmas = self.density_scale * sigmas
+            if self.density_scale != 1:                                # (x * 1 is x: two launches per step that change nothing)
+                sigmas = self.density_scale * sigmas
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image, depth = mix_background(weights_sum, depth, image, nears, fars, bg_color)
             results["weights_sum"] = weights_sum
         else:
             weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
@@ -169,8 +219,7 @@ class NGPRenderer(nn.Module):
                 packed, cnt = raymarching.compact_alive(rays_alive, n_alive)
                 rays_alive = packed[: int(cnt.item())]
                 step += n_step
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image, depth = mix_background(weights_sum, depth, image, nears, fars, bg_color)
             results["weights_sum"] = weights_sum
 
         results["depth"] = depth.view(*prefix)

@@ -156,6 +156,55 @@ class GradExchange:
         return self._events[0].elapsed_time(self._events[1])
 
 
+class _LeanLambdaLR(torch.optim.lr_scheduler.LambdaLR):
+    """main_nerf.py:131 `LambdaLR(optimizer, lambda iter: 0.1 ** min(iter / opt.iters, 1))` with a `step()` that only does the arithmetic (the stock one
+    spends 0.1 ms per call on bookkeeping: a tenth of this training step's host time).  Same state, same state_dict, same learning rates."""
+
+    def step(self, epoch=None):
+        if epoch is not None:
+            return super().step(epoch)
+        self._step_count += 1
+        self.last_epoch += 1
+        lrs = [base * fn(self.last_epoch) for base, fn in zip(self.base_lrs, self.lr_lambdas)]
+        for group, lr in zip(self.optimizer.param_groups, lrs):
+            group["lr"] = lr
+        self._last_lr = lrs
+
+
+class _mse_head(torch.autograd.Function):
+    """loss = mean((pred - target)^2) (nerf/utils.py:450,480) and loss * scale (:789 scaler.scale(loss)) in ONE launch that also leaves the
+    gradient with respect to pred for a unit incoming gradient; backward is one more launch (csrc/train_head.hip).  Returns (loss, scaled loss);
+    differentiate the scaled one.  `scale`: a 1-element float32 device tensor or None."""
+    _ws = {}
+
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        import ngp_hip as _hip
+        p, t = pred.contiguous(), target.contiguous().to(torch.float32)
+        dev = p.device
+        ws = _mse_head._ws.get(dev)
+        if ws is None:
+            ws = _mse_head._ws[dev] = torch.zeros(int(_hip.lib().ngp_mse_head_workspace()), dtype=torch.uint8, device=dev)
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        unit = torch.empty_like(p)
+        _hip.check(_hip.lib().ngp_mse_head_forward(_hip.ptr(p), _hip.ptr(t), p.numel(), _hip.ptr(scale), _hip.ptr(loss), _hip.ptr(unit), _hip.ptr(ws),
+                                                   ws.numel(), _hip.stream()), "mse_head_forward")
+        ctx.save_for_backward(unit, scale)
+        ctx.shape = pred.shape
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_scaled):
+        import ngp_hip as _hip
+        unit, scale = ctx.saved_tensors
+        g = torch.empty_like(unit)
+        gl = g_loss.contiguous().float() if g_loss is not None else None
+        gs = g_scaled.contiguous().float() if g_scaled is not None else None
+        _hip.check(_hip.lib().ngp_mse_head_backward(_hip.ptr(unit), _hip.ptr(gl), _hip.ptr(gs), _hip.ptr(scale), unit.numel(), _hip.ptr(g),
+                                                    _hip.stream()), "mse_head_backward")
+        return g.view(ctx.shape), None, None
+
+
 class WeightEMA:
     """Exponential moving average of the parameters, as the reference's Trainer keeps it (nerf/utils.py:324-325: torch_ema's
     ExponentialMovingAverage(model.parameters(), decay=0.95); updated once per epoch :814-815 and per GUI burst :683-684; evaluation and the
@@ -213,9 +262,11 @@ class WeightEMA:
 
 class NGPTrainer:
     def __init__(self, renderer, lr=1e-2, iters=30000, fp16=True, update_extra_interval=16, seed=0, fused_adam=None, ema_decay=0.95,
-                 steps_per_epoch=None, time_exchange=False):
+                 steps_per_epoch=None, time_exchange=False, native_adam=None):
         """ema_decay: None disables the average (main_nerf.py:135 passes 0.95).  steps_per_epoch: the reference updates the average once per
-        epoch = once per pass over the training views (nerf/utils.py:814-815); with a number here `step()` calls `end_epoch()` itself."""
+        epoch = once per pass over the training views (nerf/utils.py:814-815); with a number here `step()` calls `end_epoch()` itself.
+        native_adam: Adam + GradScaler as three native launches (ngp/optim.py, csrc/adam.hip); default on a GPU model, never on a CPU one
+        (the gloo rehearsal runs torch's classes: same recurrences, same state_dict layouts)."""
         self.ren = renderer
         self.fp16 = fp16
         self.iters = iters
@@ -228,9 +279,19 @@ class NGPTrainer:
         # not stalled once per step and can queue the next step's launches behind the running one.
         if fused_adam is None:
             fused_adam = self.device_type == "cuda"
-        self.opt = torch.optim.Adam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=bool(fused_adam))
-        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
-        self.scaler = torch.amp.GradScaler(self.device_type, enabled=fp16)
+        if native_adam is None:
+            native_adam = self.device_type == "cuda" and all(p.dtype == torch.float32 and p.is_contiguous() for p in renderer.field.parameters())
+        self.native_adam = bool(native_adam)
+        if self.native_adam:
+            # ... and the native one (default): the non-finite check, GradScaler's decisions and recurrence, Adam and the float16 copy of the
+            # parameters the next forward reads, in three launches with nothing read back (0.20 -> 0.09 ms of the step, ngp/optim.py)
+            from .optim import NativeAdam, NativeScaler
+            self.opt = NativeAdam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15, scaler_enabled=fp16)
+            self.scaler = NativeScaler(self.opt)
+        else:
+            self.opt = torch.optim.Adam(renderer.field.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=bool(fused_adam))
+            self.scaler = torch.amp.GradScaler(self.device_type, enabled=fp16)
+        self.sched = _LeanLambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.exchange = GradExchange(list(renderer.field.parameters()), timing=time_exchange)
         self.ema = WeightEMA(renderer.field.parameters(), decay=ema_decay) if ema_decay is not None else None
         self.global_step = 0
@@ -239,11 +300,13 @@ class NGPTrainer:
 
     def step(self, rays_o, rays_d, target, bg_color=1, **march):
         """One optimisation step on a [1, N, 3] ray batch; returns the (unscaled) loss as a tensor."""
-        ren = self.ren.train()
+        ren = self.ren if self.ren.training else self.ren.train()
         if self.global_step % self.update_extra_interval == 0:
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 ren.update_extra_state()
-        self.opt.zero_grad(set_to_none=True)
+        for group in self.opt.param_groups:              # = opt.zero_grad(set_to_none=True) without its profiler range and foreach bookkeeping (30 us per step)
+            for p in group["params"]:
+                p.grad = None
         self.exchange.begin_step()
         field = ren.field
         if hasattr(field, "grad_sink"):
@@ -251,21 +314,61 @@ class NGPTrainer:
         try:
             with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
                 out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)
-                loss = torch.nn.functional.mse_loss(out["image"], target)
-            self.scaler.scale(loss).backward()
+                image = out["image"]
+                if self.native_adam and image.is_cuda and image.dtype == torch.float32 and image.numel() > 0 and image.shape == target.shape:
+                    # loss, scaled loss and d loss / d image in one launch (the scale stays on the device: ngp/optim.py)
+                    scale = self.opt._state_on(image.device)[:1] if self.fp16 else None
+                    loss, scaled = _mse_head.apply(image, target, scale)
+                else:
+                    loss = torch.nn.functional.mse_loss(image, target)
+                    scaled = None
+            (scaled if scaled is not None else self.scaler.scale(loss)).backward()
         finally:
             if hasattr(field, "grad_sink"):
                 field.grad_sink = None
         self.exchange()                              # gradients are still scaled; the scale is identical on every rank
-        self.scaler.step(self.opt)
-        self.scaler.update()
-        if hasattr(field, "mark_updated"):
-            field.mark_updated()                     # parameters changed (fused Adam does not say so through `_version`)
+        if self.native_adam:
+            # the update launch also writes the half copies the field's native kernels read (otherwise the next forward converts the table again)
+            mirrored = self.fp16 and getattr(field, "fused_training", False) and hasattr(field, "half_mirrors") and field._fused_shape_ok()
+            self.opt.half_mirrors = field.half_mirrors() if mirrored else {}
+            self.opt.native_step()                   # = scaler.step(opt) + scaler.update()
+            if mirrored:
+                field.mirrors_are_current()
+            elif hasattr(field, "mark_updated"):
+                field.mark_updated()
+        else:
+            self.scaler.step(self.opt)
+            self.scaler.update()
+            if hasattr(field, "mark_updated"):
+                field.mark_updated()                 # parameters changed (fused Adam does not say so through `_version`)
         self.sched.step()
         self.global_step += 1
         if self.steps_per_epoch and self.global_step % self.steps_per_epoch == 0:
             self.end_epoch()
         return loss.detach()
+
+    def state_dict(self):
+        """the optimisation state under the keys of the reference's full checkpoint (nerf/utils.py:944-958), each in its class's own layout"""
+        state = {"global_step": self.global_step, "optimizer": self.opt.state_dict(), "lr_scheduler": self.sched.state_dict(),
+                 "scaler": self.scaler.state_dict()}
+        if self.ema is not None:
+            state["ema"] = self.ema.state_dict()
+        return state
+
+    def load_state_dict(self, state):
+        """nerf/utils.py:1036-1060 (there every part is optional and a failure to load one is a warning; here a part that is present must load)"""
+        self.global_step = int(state.get("global_step", self.global_step))
+        if "optimizer" in state:
+            self.opt.load_state_dict(state["optimizer"])
+        if "lr_scheduler" in state:
+            self.sched.load_state_dict(state["lr_scheduler"])
+        if "scaler" in state and state["scaler"]:
+            self.scaler.load_state_dict(state["scaler"])
+        if self.ema is not None and "ema" in state:
+            self.ema.load_state_dict(state["ema"])
+        field = self.ren.field
+        if hasattr(field, "mark_updated"):
+            field.mark_updated()
 
     def end_epoch(self):
         """nerf/utils.py:814-815: the moving average follows the weights once per epoch"""

@@ -133,9 +133,11 @@ class _march_rays_train(Function):
                 mean_count += align - mean_count % align
             M = mean_count
 
-        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        # the reference allocates these with torch.zeros (raymarching.py:205-207: three whole-buffer fills per step); the native call zeroes the slots no
+        # ray fills itself (ngp_march_rays_train_filled: they form one tail), so the contents are the same
+        xyzs = torch.empty(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.empty(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.empty(M, 2, dtype=rays_o.dtype, device=dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -144,7 +146,7 @@ class _march_rays_train(Function):
         # with room for every sample's t (N * max_steps floats, up to 256 MiB) the second pass does not march again
         full = L.ngp_march_rays_train_workspace_full(N, max_steps)
         ws = _hip.workspace(full if full <= (256 << 20) else L.ngp_march_rays_train_workspace(N), dev)
-        _hip.check(L.ngp_march_rays_train(_hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), bound, dt_gamma,
+        _hip.check(L.ngp_march_rays_train_filled(_hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), bound, dt_gamma,
                                           max_steps, N, C, H, M, _hip.ptr(nears.contiguous()), _hip.ptr(fars.contiguous()),
                                           _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays),
                                           _hip.ptr(step_counter), int(perturb), _hip.ptr(ws), ws.numel(), _hip.stream()),

@@ -282,8 +282,9 @@ def test_grid_input_gradient_without_dy_dx_is_bit_identical(dev, half, level_dim
             outside = ((x < -1) | (x > 1)).any(dim=-1)
             assert outside.sum() > 100 and (g1[outside] == 0).all()
             if not frozen:
-                # the same scatter both times; atomics make the sum order-dependent (half2 atomics round every partial sum)
-                assert (t0 - t1).abs().max() <= (5e-3 if half else 1e-5) * t0.abs().max()
+                # the same scatter both times; atomics make the sum order-dependent (half2 atomics round every partial sum: ~36 adds per coarse row here,
+                # each good to 2^-11 of the running sum; 5e-3 was exceeded once in about ten full runs of the suite, on C = 4 where runs are not pre-merged)
+                assert (t0 - t1).abs().max() <= (1.5e-2 if half else 1e-5) * t0.abs().max()
     finally:
         G.RECOMPUTE_INPUT_GRAD, G.RECOMPUTE_MIN_POINTS = True, 32768
         enc.embeddings.requires_grad_(True)

@@ -56,3 +56,33 @@ def test_trainer_epochs_update_the_average_and_eval_uses_it():
     assert off.ema is None
     with off.eval_weights():
         pass
+
+
+def test_cpu_trainer_uses_torch_classes_and_its_state_round_trips():
+    """a CPU model never gets the native optimiser (there is no CPU path in ngp/optim.py); the trainer's state has the reference's checkpoint keys
+    (nerf/utils.py:944-958) and a second trainer resumes from it"""
+    import pytest
+    from ngp.optim import NativeAdam
+    ren = _MockRenderer()
+    tr = NGPTrainer(ren, lr=1e-2, iters=50, fp16=False, update_extra_interval=4, seed=1, ema_decay=0.95, steps_per_epoch=3)
+    assert not tr.native_adam and type(tr.opt) is torch.optim.Adam and isinstance(tr.scaler, torch.amp.GradScaler)
+    with pytest.raises(ValueError, match="no CPU path"):
+        NativeAdam(ren.field.parameters())
+    g = torch.Generator().manual_seed(3)
+    batch = lambda: (torch.rand(1, 64, 3, generator=g), torch.randn(1, 64, 3, generator=g), torch.rand(1, 64, 3, generator=g))   # noqa: E731
+    for _ in range(7):
+        tr.step(*batch())
+    import copy
+    state = copy.deepcopy(tr.state_dict())           # what a torch.save / torch.load round trip gives: own tensors (load_state_dict adopts the ones it is handed)
+    assert set(state) == {"global_step", "optimizer", "lr_scheduler", "scaler", "ema"} and state["global_step"] == 7
+    ren2 = _MockRenderer()
+    ren2.load_state_dict(ren.state_dict())
+    tr2 = NGPTrainer(ren2, lr=1e-2, iters=50, fp16=False, update_extra_interval=4, seed=1, ema_decay=0.95, steps_per_epoch=3)
+    tr2.load_state_dict(state)
+    assert tr2.global_step == 7 and tr2.ema.num_updates == tr.ema.num_updates == 2
+    assert tr2.sched.get_last_lr() == tr.sched.get_last_lr()
+    b = batch()
+    l1, l2 = tr.step(*b), tr2.step(*b)
+    assert torch.equal(l1, l2)
+    for p, q in zip(ren.field.parameters(), ren2.field.parameters()):
+        assert torch.equal(p, q)
