@@ -146,7 +146,7 @@ def bench_train(args, rank, world, dev, W, teacher):
             t0 = time.perf_counter()
             for k in range(count):
                 loss = step(first + k)
-            queued = time.perf_counter() - t0                                  # the host has queued every launch; the GPU may still be running
+            queued = time.perf_counter() - t0                                  # the host has queued every launch (an upper bound of the host's need: the runtime lets it run only a few launches ahead)
             sync_all()
             elapsed = time.perf_counter() - t0
         scatter_ms, calls = ngp_hip.timer_ms("grid_encode_backward")

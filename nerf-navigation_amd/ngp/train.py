@@ -156,6 +156,28 @@ class GradExchange:
         return self._events[0].elapsed_time(self._events[1])
 
 
+class _Ctx:
+    """What the body of a torch.autograd.Function asks of its `ctx`, for calling `forward` / `backward` directly: NGPTrainer's direct step runs the SAME
+    function bodies as the autograd graph, in the order the engine would, without building the graph (five Function.apply + the engine are ~0.35 ms of host
+    time per step, and the step is host-bound)."""
+    __slots__ = ("saved_tensors", "needs_input_grad", "__dict__")
+
+    def __init__(self, needs_input_grad=()):
+        self.saved_tensors, self.needs_input_grad = (), tuple(needs_input_grad)
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def _body(fn):
+    """the undecorated forward / backward of a Function (custom_fwd / custom_bwd keep it as __wrapped__): the direct step runs outside autocast on float32
+    operands, which is what those decorators arrange"""
+    return getattr(fn, "__wrapped__", fn)
+
+
 class _LeanLambdaLR(torch.optim.lr_scheduler.LambdaLR):
     """main_nerf.py:131 `LambdaLR(optimizer, lambda iter: 0.1 ** min(iter / opt.iters, 1))` with a `step()` that only does the arithmetic (the stock one
     spends 0.1 ms per call on bookkeeping: a tenth of this training step's host time).  Same state, same state_dict, same learning rates."""
@@ -262,11 +284,14 @@ class WeightEMA:
 
 class NGPTrainer:
     def __init__(self, renderer, lr=1e-2, iters=30000, fp16=True, update_extra_interval=16, seed=0, fused_adam=None, ema_decay=0.95,
-                 steps_per_epoch=None, time_exchange=False, native_adam=None):
+                 steps_per_epoch=None, time_exchange=False, native_adam=None, direct=True):
         """ema_decay: None disables the average (main_nerf.py:135 passes 0.95).  steps_per_epoch: the reference updates the average once per
         epoch = once per pass over the training views (nerf/utils.py:814-815); with a number here `step()` calls `end_epoch()` itself.
         native_adam: Adam + GradScaler as three native launches (ngp/optim.py, csrc/adam.hip); default on a GPU model, never on a CPU one
-        (the gloo rehearsal runs torch's classes: same recurrences, same state_dict layouts)."""
+        (the gloo rehearsal runs torch's classes: same recurrences, same state_dict layouts).
+        direct: run forward, loss and backward of the default GPU configuration (FFMLP field, fp16, native optimiser, scalar background) as straight-line
+        calls of the autograd functions' bodies instead of through the autograd engine (`_direct_forward_backward`); False = always autograd."""
+        self.direct, self._one = bool(direct), None
         self.ren = renderer
         self.fp16 = fp16
         self.iters = iters
@@ -298,6 +323,58 @@ class NGPTrainer:
         # the same pcg32 seed on every rank keeps the density grids of the replicas identical
         renderer.grid_seed = int(seed)
 
+    # ---- the direct step: the autograd graph's function bodies, called in order ---------------------------------------------------------------
+    def _direct_applies(self, ren, field, rays_o, target, bg_color, march):
+        from .field import NGPFieldFF
+        p = getattr(getattr(field, "encoder", None), "embeddings", None)
+        return (self.direct and self.native_adam and self.fp16 and isinstance(field, NGPFieldFF) and field.fused_training and ren.cuda_ray
+                and getattr(ren, "bg_radius", -1) <= 0 and rays_o.is_cuda and rays_o.dtype == torch.float32 and target.dtype == torch.float32
+                and isinstance(bg_color, (int, float)) and p is not None and p.requires_grad and p.dtype == torch.float32
+                and field.sigma_net.weights.requires_grad and field.color_net.weights.requires_grad and field._fused_shape_ok()
+                and set(march) <= {"dt_gamma", "max_steps"} and rays_o.numel() > 0)
+
+    @torch.no_grad()
+    def _direct_forward_backward(self, ren, field, rays_o, rays_d, target, bg_color, dt_gamma=0, max_steps=1024):
+        """`run_cuda`'s training branch (ngp/render.py, nerf/renderer.py:282-321), the loss and the whole backward as straight-line calls of the function
+        bodies the autograd route runs (raymarching._march_rays_train, field._field_train, raymarching._composite_rays_train, render._mix_background,
+        _mse_head): same launches, same order, same values; the gradients end up in `.grad` (or with the exchange, as there).  Returns the loss."""
+        import raymarching
+        from raymarching import raymarching as RM
+        from .field import _field_train
+        from .render import _mix_background
+        o, d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        nears, fars = raymarching.near_far_from_aabb(o, d, ren._aabb(), ren.min_near)
+        counter = ren.step_counter[ren.local_step % 16]
+        counter.zero_()
+        ren.local_step += 1
+        xyzs, dirs, deltas, rays = _body(RM._march_rays_train.forward)(_Ctx(), o, d, ren.bound, ren.density_bitfield, ren.cascade, ren.grid_size, nears, fars,
+                                                                      counter, ren.mean_count, True, 128, False, dt_gamma, max_steps)
+        emb, w_s, w_c = field.encoder.embeddings, field.sigma_net.weights, field.color_net.weights
+        c_field = _Ctx((False, False, True, True, True, False))
+        sigmas, rgbs = _body(_field_train.forward)(c_field, xyzs, dirs, emb, w_s, w_c, field)
+        scale_sigma = ren.density_scale != 1
+        c_comp = _Ctx((True, True, False, False))
+        weights_sum, depth, image = _body(RM._composite_rays_train.forward)(c_comp, ren.density_scale * sigmas if scale_sigma else sigmas, rgbs, deltas, rays)
+        c_mix = _Ctx()
+        mixed, _ = _mix_background.forward(c_mix, weights_sum, depth, image, nears, fars, bg_color)
+        c_loss = _Ctx()
+        both = _mse_head.forward(c_loss, mixed.view(target.shape), target, self.opt._state_on(mixed.device)[:1])
+        # ---- backward, in the engine's order ----
+        if self._one is None or self._one.device != mixed.device:
+            self._one = torch.ones(1, dtype=torch.float32, device=mixed.device)
+        g_mixed = _mse_head.backward(c_loss, None, self._one)[0]
+        g_ws, _, g_image, _, _, _ = _mix_background.backward(c_mix, g_mixed.view(-1, 3), None)
+        g_sig, g_rgb, _, _ = _body(RM._composite_rays_train.backward)(c_comp, g_ws, None, g_image)
+        if scale_sigma:
+            g_sig = g_sig * ren.density_scale
+        grads = _body(_field_train.backward)(c_field, g_sig, g_rgb)
+        if grads[2] is not None:                     # without a gradient exchange: what autograd's AccumulateGrad would do on cleared gradients
+            emb.grad, w_s.grad, w_c.grad = grads[2].view_as(emb), grads[3].view_as(w_s), grads[4].view_as(w_c)
+        field._param_epoch += 1                      # the post-accumulate-grad hooks of the autograd route (ngp/field.py _watch_parameters, gridencoder drop_half_table)
+        field._mirror_ok = False
+        emb._ngp_half = None
+        return both[0]
+
     def step(self, rays_o, rays_d, target, bg_color=1, **march):
         """One optimisation step on a [1, N, 3] ray batch; returns the (unscaled) loss as a tensor."""
         ren = self.ren if self.ren.training else self.ren.train()
@@ -312,17 +389,20 @@ class NGPTrainer:
         if hasattr(field, "grad_sink"):
             field.grad_sink = self.exchange if self.exchange.active() else None     # the native backward hands its gradients over as they appear
         try:
-            with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
-                out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)
-                image = out["image"]
-                if self.native_adam and image.is_cuda and image.dtype == torch.float32 and image.numel() > 0 and image.shape == target.shape:
-                    # loss, scaled loss and d loss / d image in one launch (the scale stays on the device: ngp/optim.py)
-                    scale = self.opt._state_on(image.device)[:1] if self.fp16 else None
-                    loss, scaled = _mse_head.apply(image, target, scale)
-                else:
-                    loss = torch.nn.functional.mse_loss(image, target)
-                    scaled = None
-            (scaled if scaled is not None else self.scaler.scale(loss)).backward()
+            if self._direct_applies(ren, field, rays_o, target, bg_color, march):
+                loss = self._direct_forward_backward(ren, field, rays_o, rays_d, target, bg_color, **march)
+            else:
+                with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):
+                    out = ren.run_cuda(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **march)
+                    image = out["image"]
+                    if self.native_adam and image.is_cuda and image.dtype == torch.float32 and image.numel() > 0 and image.shape == target.shape:
+                        # loss, scaled loss and d loss / d image in one launch (the scale stays on the device: ngp/optim.py)
+                        scale = self.opt._state_on(image.device)[:1] if self.fp16 else None
+                        loss, scaled = _mse_head.apply(image, target, scale)
+                    else:
+                        loss = torch.nn.functional.mse_loss(image, target)
+                        scaled = None
+                (scaled if scaled is not None else self.scaler.scale(loss)).backward()
         finally:
             if hasattr(field, "grad_sink"):
                 field.grad_sink = None
