@@ -9,6 +9,7 @@
 // Arithmetic is the reference's, operation for operation: positions and weights in binary32, accumulation in the
 // table dtype (c10::Half arithmetic = compute in float, round to half after every operation).
 #include "ngp_device.h"
+#include <atomic>
 
 static constexpr uint32_t GE_MAX_LEVELS = 32;
 
@@ -751,7 +752,8 @@ static gs_ws gs_layout(uint32_t B, uint32_t L) {
 __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
                                                  uint32_t* __restrict__ g_vals, uint16_t* __restrict__ g_rows, uint16_t* __restrict__ g_dir,
                                                  uint32_t B, uint32_t first, uint32_t count, uint32_t nchunks, ge_levels lv, uint32_t gridtype,
-                                                 bool align_corners) {
+                                                 bool align_corners, uint32_t* __restrict__ ticket) {
+    if (ticket && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *ticket = 0u;       // for the k_gs_accumulate that follows on the stream (saves a memset launch)
     __shared__ uint32_t s_vals[GS_REGION];             // 32 KiB: the region, slice-sorted
     __shared__ uint16_t s_rows[GS_REGION];             // 16 KiB
     __shared__ uint32_t s_hist[GS_MAX_SLICES + 1];     // entries per slice, then (after the scan) first entry of each slice
@@ -1006,7 +1008,19 @@ static int gs_run(const char* who, const void* grad, const float* inputs, const 
         lds_ok = true;
     }
     int cus = 256;
-    { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; }
+    {   // (hipGetDeviceProperties fills a 1.5 KB structure through the driver on every call: asked once per device)
+        static std::atomic<int> cu_count[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            int c = cu_count[dev].load(std::memory_order_relaxed);
+            if (c == 0) {
+                hipDeviceProp_t p;
+                c = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+                cu_count[dev].store(c, std::memory_order_relaxed);
+            }
+            cus = c;
+        }
+    }
     uint32_t first = 0;
     bool add = false;
     do {                                               // B == 0: one pass that writes zeros (the whole table is always written)
@@ -1014,9 +1028,11 @@ static int gs_run(const char* who, const void* grad, const float* inputs, const 
         const uint32_t nchunks = count ? ngp_div_up(count, GS_CHUNK) : 0u;
         if (do_bin && nchunks)
             hipLaunchKernelGGL(k_gs_bin, dim3(nchunks, L), dim3(GS_CHUNK), 0, s, (const _Float16*)grad, inputs, offsets, (uint32_t*)(base + w.vals),
-                               (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0);
+                               (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0,
+                               do_sum ? (uint32_t*)(base + w.ticket) : (uint32_t*)nullptr);
         if (do_sum) {
-            if (hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "%s: memset failed", who);
+            // the ticket starts at zero: the bin launch just before wrote it, otherwise (no bin launch in this call) a memset does
+            if (!(do_bin && nchunks) && hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "%s: memset failed", who);
             if (out_dtype == NGP_F32)
                 hipLaunchKernelGGL(k_gs_accumulate<float>, dim3(cus), dim3(1024), lds, s, (const uint32_t*)(base + w.vals), (const uint16_t*)(base + w.rows),
                                    (const uint16_t*)(base + w.dir), offsets, (uint32_t*)(base + w.ticket), (float*)grad_embeddings, level_lo, level_hi, nchunks,
