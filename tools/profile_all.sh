@@ -1,5 +1,5 @@
 # Collect and summarise the tracked profiles on the GPU box in one gpurun call; summaries land in gpurun_out/profiles_r15 (copy them to profiles/).
-#   gpurun -- 'bash tools/profile_all.sh [frame] [train] [perop] [nav] [trained]'       (default: all five)
+#   gpurun -- 'bash tools/profile_all.sh [frame] [train] [steady] [perop] [nav] [trained]'       (default: all but steady)
 set -e
 D=gpurun_out/profiles_r15
 WHAT="${@:-frame train perop nav trained}"
@@ -14,6 +14,18 @@ for w in $WHAT; do
       python tools/summarize_profiles.py r15_train k_gs_bin k_gs_accumulate k_field_train_forward k_field_train_backward k_composite_train k_march_train k_dg_ --sources train --dst $D --top 30 \
         --title "bench.py --mode train --steps 16 --warmup 4 --settle 64 (4,096-ray steps on the early, nearly full occupancy grid), 1x MI355X" > gpurun_out/sum_train.log 2>&1
       rm -rf gpurun_out/r15_train_kt gpurun_out/r15_train_pmc? ;;
+    steady)
+      # the steady state of training (grid converged, ~0.65 M points per step): kernel trace only, summarised over the last 24 steps + one step's timeline
+      mkdir -p $D
+      R=$(pwd); ( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/r15_steady_kt && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r15_steady_kt -- python3 $R/bench.py --mode train --steps 32 --warmup 4 --settle 1500 --no-cpu > $R/gpurun_out/r15_steady_kt.log 2>&1 )
+      { echo "# r15_train_steady: bench.py --mode train --steps 32 --warmup 4 --settle 1500 under rocprofv3 --kernel-trace, 1x MI355X; kernel sources $(python -c 'import bench; print(bench.sources_sha16(bench.TRAIN_SOURCES))')"
+        echo; echo "The command's own line: \`$(grep '^{"metric"' gpurun_out/r15_steady_kt.log | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print("%.3f ms per step, %.2f M rays/s, %.0f points per step" % (d["ms_per_step"], d["value"]/1e6, d["config"]["points_per_step"]))')\`"
+        echo; echo '## GPU time per step, last 24 steps (`tools/last_steps_kernel_stats.py`)'; echo; echo '```'
+        python tools/last_steps_kernel_stats.py gpurun_out/r15_steady_kt/*/*kernel_trace.csv 24 60
+        echo '```'; echo; echo '## One step, launch by launch (start since the compositor, duration, gap to the previous launch; us)'; echo; echo '```'
+        python tools/one_step_timeline.py gpurun_out/r15_steady_kt/*/*kernel_trace.csv
+        echo '```'; } > $D/r15_train_steady_summary.md
+      rm -rf gpurun_out/r15_steady_kt ;;
     perop)
       bash tools/profile_round.sh r15_perop short -- bench.py --path per_op --no-cpu --no-fit --frames-per-launch 1 --steps 8 --warmup 2
       python tools/summarize_profiles.py r15_perop k_march_rays k_grid_forward k_ffmlp_forward k_composite_rays k_compact --dst $D --top 30 \
