@@ -36,6 +36,7 @@ def _mock_devices(monkeypatch, current=0):
     monkeypatch.setattr(torch.cuda, "device", device)
     monkeypatch.setattr(torch.cuda, "current_stream",
                         lambda d=None: types.SimpleNamespace(cuda_stream=0xA000 + (state["current"] if d is None else torch.device(d).index)))
+    monkeypatch.setattr(hip, "_raw_stream", lambda index: 0xA000 + int(index))    # the raw handle of that device's current stream (ngp_hip._raw_stream)
     return state
 
 
