@@ -203,3 +203,37 @@ def test_direct_step_equals_the_autograd_step(dev):
     emb = a.field._fused["tensors"][0]
     assert torch.equal(emb, a.field.encoder.embeddings.detach().to(torch.float16))    # mirrors current after direct steps too
     assert a.mean_count == b.mean_count or abs(a.mean_count - b.mean_count) <= 0.05 * b.mean_count
+
+
+@pytest.mark.parametrize("field_kind,fp16", [("linear", False), ("linear", True), ("ff", False)], ids=["nn_linear_fp32", "nn_linear_fp16", "ffmlp_fp32"])
+def test_trainer_configurations_outside_the_direct_step_learn_with_the_native_optimiser(dev, field_kind, fp16):
+    """the default nn.Linear field (six parameter tensors, no resident half copies) and float32 training go through autograd + NativeAdam:
+    the loss falls, the optimiser counts the steps, nothing is left stale for a frozen-model render afterwards"""
+    from ngp import workload as W
+    from ngp.field import NGPField, NGPFieldFF
+    from ngp.render import NGPRenderer
+    from ngp.train import NGPTrainer
+    teacher = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(W.make_model(0)), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev).eval()
+    teacher.load_density_grid(W.density_grid())
+    res, n_rays = 48, 1024
+    o, d = W.get_rays(W.orbit_pose(2, 8), W.intrinsics(res, res), res, res)
+    to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+    tc = teacher.render_fused(to, td, bg_color=1, image_width=res)["image"]
+    torch.manual_seed(0)
+    field = (NGPField if field_kind == "linear" else NGPFieldFF)(bound=W.BOUND).to(dev)
+    student = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
+    tr = NGPTrainer(student, lr=1e-2, iters=600, fp16=fp16)
+    assert tr.native_adam and not tr._direct_applies(student, field, to, tc, 1, {"max_steps": 256})
+    gen = torch.Generator(device=dev).manual_seed(1)
+    losses = []
+    for k in range(60):
+        idx = torch.randint(0, res * res, (n_rays,), device=dev, generator=gen)
+        losses.append(float(tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=256)))
+    assert np.isfinite(losses).all() and min(losses[-5:]) < 0.7 * max(losses[:5]), losses
+    assert tr.opt.step_count() == 60 and tr.scaler.get_scale() == (65536.0 if fp16 else 1.0)
+    student.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+        a = student.run_cuda(to, td, bg_color=1, max_steps=256)["image"].clone()
+        field.mark_updated()                                                           # drops every cached copy: the same image must come out
+        b = student.run_cuda(to, td, bg_color=1, max_steps=256)["image"]
+    assert torch.equal(a, b)
