@@ -1,5 +1,5 @@
 """GPU: the fused frame of a FITTED model against the CPU oracle (every other pipeline test renders the hand-set model).
-A fresh field is trained for 300 steps on 64x64 teacher views with the package's trainer (native field launches, binned scatter, fused Adam,
+A fresh field is trained for 300 steps on 64x64 teacher views with the package's trainer (native field launches, binned scatter, native Adam + GradScaler,
 grid refresh every 16 steps, weight EMA), then one view is rendered by ngp_render_frame and by oracle.render_oracle.render_single_march with
 the student's parameters and its LEARNED occupancy grid: per-ray sample counts, image, and the PSNR difference against the teacher."""
 import importlib
