@@ -34,7 +34,8 @@ def read_checkpoint_full(path):
     order is the model's; `ngp.train.WeightEMA.load_state_dict` takes it as it is."""
     blob = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(blob, dict) and "model" in blob:
-        return blob["model"], {k: blob[k] for k in ("mean_count", "mean_density", "epoch", "global_step", "ema") if k in blob}
+        return blob["model"], {k: blob[k] for k in ("mean_count", "mean_density", "epoch", "global_step", "ema", "optimizer", "lr_scheduler", "scaler", "stats")
+                               if k in blob}
     return blob, {}
 
 
@@ -131,3 +132,35 @@ def to_reference_state_dict(renderer):
         if hasattr(renderer, k) and torch.is_tensor(getattr(renderer, k)):
             sd[k] = getattr(renderer, k).detach().clone()
     return sd
+
+
+def write_checkpoint(path, renderer, trainer=None, epoch=0, stats=None, full=True):
+    """Trainer.save_checkpoint (nerf/utils.py:938-986) for an NGPRenderer and (full=True) the optimisation state of an ngp.train.NGPTrainer: one file with
+    the reference's keys -- epoch, global_step, stats, mean_count, mean_density, [optimizer, lr_scheduler, scaler, ema,] model -- each part in the layout of
+    the class the reference uses for it (torch.optim.Adam, LambdaLR, GradScaler, torch_ema), so the reference's load_checkpoint reads it and
+    `resume_trainer` reads the reference's.  Written with torch.save; every value is a tensor, a number, a string or a container of those, so
+    torch.load(weights_only=True) reads it back."""
+    state = {"epoch": int(epoch), "global_step": int(trainer.global_step) if trainer is not None else 0, "stats": stats if stats is not None else {}}
+    if getattr(renderer, "cuda_ray", False):
+        state["mean_count"], state["mean_density"] = int(renderer.mean_count), float(renderer.mean_density)
+    if full and trainer is not None:
+        t = trainer.state_dict()
+        state["optimizer"], state["lr_scheduler"], state["scaler"] = t["optimizer"], t["lr_scheduler"], t["scaler"]
+        if "ema" in t:
+            state["ema"] = t["ema"]
+    state["model"] = to_reference_state_dict(renderer)
+    torch.save(state, path)
+    return state
+
+
+def resume_trainer(path, renderer, trainer):
+    """Trainer.load_checkpoint (nerf/utils.py:1002-1060) for a file of write_checkpoint or of the reference (same field type as `renderer.field`): model
+    and renderer buffers, mean_count / mean_density, and whatever optimisation state the file holds.  Returns the epoch stored in it."""
+    field_sd_all, extra = read_checkpoint_full(path)
+    field_sd, ren_sd = split_state_dict(field_sd_all)
+    renderer.field.load_state_dict(field_sd)
+    if hasattr(renderer.field, "mark_updated"):
+        renderer.field.mark_updated()
+    load_renderer_buffers(renderer, ren_sd, extra)
+    trainer.load_state_dict({k: extra[k] for k in ("global_step", "optimizer", "lr_scheduler", "scaler", "ema") if k in extra})
+    return int(extra.get("epoch", 0))
