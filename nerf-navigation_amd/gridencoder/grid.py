@@ -29,6 +29,23 @@ RECOMPUTE_MIN_POINTS = 32768
 BINNED_SCATTER = True
 # True: D = 3, C = 2 forwards write [B, L*C] directly (ngp_grid_encode_forward_rows) instead of [L, B, C] + permute copy.  Same bits.
 ROWS_FORWARD = True
+# ... except where the caller says its points are incoherent (`with level_major_forward():`, the occupancy-grid refresh's random points): then the
+# reference's level-major kernel + permute copy is faster, because one level's table (2 MB) at a time stays in an XCD's 4 MiB L2 while the row kernel
+# has all 16 levels (25 MB) live at once (tools/time_grid_level_major.py: 2.1 M random points 0.97 against 1.26 ms; 640 k coherent points 0.14 against 0.10).
+_LEVEL_MAJOR_DEPTH = 0
+
+
+class level_major_forward:
+    """context manager: D = 3, C = 2 forwards inside take the level-major kernel + permute (same bits as the row kernel)"""
+
+    def __enter__(self):
+        global _LEVEL_MAJOR_DEPTH
+        _LEVEL_MAJOR_DEPTH += 1
+
+    def __exit__(self, *exc):
+        global _LEVEL_MAJOR_DEPTH
+        _LEVEL_MAJOR_DEPTH -= 1
+        return False
 
 
 # The reference converts the float32 table to half on EVERY autocast forward (grid.py:38-39: 50 MB read + 25 MB written per call, 64
@@ -144,7 +161,7 @@ class _grid_encode(Function):
 
         # the row kernel stages 256 x (L + 1) feature pairs in LDS: it takes tables whose tile fits the default 64 KiB (csrc/gridencoder.hip)
         rows_fit = 256 * (L + 1) * 2 * embeddings.element_size() <= 65536
-        if ROWS_FORWARD and D == 3 and C == 2 and rows_fit and not (calc_grad_inputs and not recompute):
+        if ROWS_FORWARD and _LEVEL_MAJOR_DEPTH == 0 and D == 3 and C == 2 and rows_fit and not (calc_grad_inputs and not recompute):
             # the reference's kernel writes [L, B, C] and grid.py:42,52 permutes + copies to [B, L*C]; this kernel writes the rows directly
             # (same bits): one launch and 2 x B x L x C values of traffic less per call
             outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 import ngp_hip as _hip
 import raymarching
+from gridencoder import grid as _grid
 
 
 def sample_pdf(bins, weights, n_samples, det=False, generator=None):
@@ -447,7 +448,8 @@ class NGPRenderer(nn.Module):
             chunk = max(int(S), 1) ** 3
             for head in range(0, n, chunk):
                 tail = min(head + chunk, n)
-                sigmas[head:tail] = self.density(xyzs[head:tail])["sigma"].reshape(-1).detach().float()
+                with _grid.level_major_forward():          # random points: one level's table at a time stays in L2 (gridencoder/grid.py)
+                    sigmas[head:tail] = self.density(xyzs[head:tail])["sigma"].reshape(-1).detach().float()
             mean = torch.empty(1, dtype=torch.float32, device=dev)
             _hip.check(L.ngp_density_grid_update(_hip.ptr(sigmas), _hip.ptr(cells), n, float(self.density_scale), float(decay),
                                                  float(self.density_thresh), cas, H, _hip.ptr(grid), _hip.ptr(self.density_bitfield),

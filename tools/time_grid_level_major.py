@@ -39,3 +39,18 @@ def run():
 for rows in (True, False):
     G.ROWS_FORWARD = rows
     print("rows kernel" if rows else "level-major + permute", "%.3f ms" % timed(run))
+# the same comparison on other point sets: uniformly random points (what the occupancy-grid refresh queries: 2.1 M per refresh) and the first
+# iteration of an 800x800 inference loop (640 k march-ordered points, one per ray: neighbouring rays, coherent)
+torch.manual_seed(0)
+sets = {"random 2.1 M": (torch.rand(2_097_152, 3, device=dev) * 2 - 1) * W.BOUND}
+o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(800, 800), 800, 800)
+o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+sets["inference iteration 640 k"] = (o + d * 1.2).clamp(-W.BOUND, W.BOUND).contiguous()
+sets["inference iteration 80 k"] = sets["inference iteration 640 k"][::8].contiguous()
+for name, pts in sets.items():
+    def run_pts():
+        with torch.autocast("cuda", dtype=torch.float16):
+            return enc(pts, bound=W.BOUND)
+    for rows in (True, False):
+        G.ROWS_FORWARD = rows
+        print(name, "| rows kernel" if rows else "| level-major + permute", "%.3f ms" % timed(run_pts))
