@@ -129,3 +129,31 @@ def test_binned_scatter_in_level_groups_equals_one_call(oracle, dev):
     assert seen4[-1][1] - seen4[-1][0] < 0.05 * int(offsets[-1])                        # with four groups the last (exposed) one is levels 0-3: 3 % of the rows
     f32 = G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False, on_group=lambda *a: None)
     assert torch.equal(f32, G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False))
+
+
+def test_binned_scatter_full_size_checksum_and_reproducibility(oracle, dev):
+    """BASELINE config 3's size (4,096 rays x up to 512 samples = 2.1 M march-ordered points, 16 levels, 2^19-row hashed levels) through properties that do not
+    need the oracle's minutes: (1) the eight trilinear weights of a sample sum to 1, so every level's column sums of the table gradient equal the column sums
+    of that level's incoming gradient over the samples inside [0,1]^3 -- a checksum of checksums, to the half rounding of the products; (2) the sums are exact
+    and order-independent: a second call gives the same bits; (3) linearity in the gradient for a power-of-two factor (to the half subnormals)."""
+    from gridencoder import grid as G
+    L = 16
+    offsets, pls = oracle.grid_offsets(3, L, 2, 2, 16, 19, 4096, False)
+    B = 4096 * 512
+    x = ray_points(4096, 512, 11)
+    rng = np.random.default_rng(12)
+    grad = (rng.normal(size=(L, B, 2)) * 0.02).astype(np.float16)
+    tg, tx, to = t(grad, dev), t(x, dev), t(offsets, dev)
+    out = G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False)
+    assert torch.equal(out, G.table_gradient_binned(tg, tx, to, B, L, np.log2(pls), 16, 0, False))      # run-to-run identical
+    inside = ((tx >= 0) & (tx <= 1)).all(dim=1)
+    want = (tg.float() * inside[None, :, None]).double().sum(dim=1).cpu().numpy()                        # [L, 2]
+    mass = (tg.float().abs() * inside[None, :, None]).double().sum(dim=1).cpu().numpy()
+    off = offsets.astype(np.int64)
+    got = np.stack([out[off[l]:off[l + 1]].double().sum(dim=0).cpu().numpy() for l in range(L)])
+    # each of the 8 products of a sample is rounded to half (2^-11 relative); the rounding errors of 16 M products of random sign mostly cancel
+    assert np.all(np.abs(got - want) <= 1e-4 * mass + 1e-6), (np.abs(got - want) / mass).max()
+    assert (np.abs(want) > 1e-3 * mass).any()                                                            # the checksum is not trivially zero
+    twice = G.table_gradient_binned((tg * 2).contiguous(), tx, to, B, L, np.log2(pls), 16, 0, False)
+    # scaling by 2 commutes with every rounding in the path except where a product falls into the half subnormals (absolute spacing 2^-24)
+    assert float((twice - out * 2).abs().max()) <= 1e-4 * float(out.abs().max())
