@@ -237,3 +237,26 @@ def test_trainer_configurations_outside_the_direct_step_learn_with_the_native_op
         field.mark_updated()                                                           # drops every cached copy: the same image must come out
         b = student.run_cuda(to, td, bg_color=1, max_steps=256)["image"]
     assert torch.equal(a, b)
+
+
+def test_native_adam_at_the_field_s_full_size(dev):
+    """the reference field's own parameter tensors (hash table 6,328,848 x 2, 7,168 and 11,264 weights): three steps beside torch.optim.Adam, the half
+    mirror of the table, and the identity on untouched rows (zero gradient, zero moments: the update is exactly zero)"""
+    mine, opt, theirs, ref, scaler = _pair(dev, [(6328848, 2), (7168,), (11264,)])
+    half = torch.empty(6328848, 2, dtype=torch.float16, device=dev)
+    opt.half_mirrors = {mine[0]: half}
+    g = torch.Generator(device=dev).manual_seed(21)
+    start = mine[0].detach().clone()
+    touched = torch.rand(6328848, device=dev, generator=g) < 0.05                      # a training batch touches a few per cent of the rows
+    for k in range(3):
+        scale = float(scaler.get_scale())
+        for a, b in zip(mine, theirs):
+            grad = torch.randn(a.shape, device=dev, generator=g) * 1e-3
+            if a.dim() == 2:
+                grad = grad * touched[:, None]
+            a.grad, b.grad = (grad * scale), (grad * scale).clone()
+        opt.step(); scaler.step(ref); scaler.update()
+        for i, (a, b) in enumerate(zip(mine, theirs)):
+            _close(a, b, f"param {i}", k)
+    assert torch.equal(mine[0].detach()[~touched], start[~touched])
+    assert torch.equal(half, mine[0].detach().to(torch.float16)) and opt.step_count() == 3
