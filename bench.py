@@ -543,6 +543,15 @@ def main():
                                                     "valu_busy_frac": (4.0 * c["SQ_ACTIVE_INST_VALU"] / (4.0 * cu_cycles)) if c.get("SQ_ACTIVE_INST_VALU") else None,
                                                     "mfma_busy_frac": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu_cycles)) if c.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                                                     "note": "what binds the kernel: the texture path and the VALU, not a memory level"}
+            if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and c.get("TCP_TCC_READ_REQ_sum"):
+                # the same launch against the chip's scattered-gather ceilings (tools/micro/gather_rate.hip, profiles/r15_gather_rate.md): the L1 tag pipe
+                # (1.55 distinct 64-byte lines per clock and CU), the L2 -> L1 line bandwidth (17 TB/s), the line rate past L2 (4.2 TB/s)
+                secs = result["roofline"]["avg_launch_ms"] * 1e-3
+                result["roofline"]["memory_levels"] = {
+                    "source": info["profile"] + " + profiles/r15_gather_rate.md",
+                    "l1_tag_lookups_per_clk_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * 2.4e9 * secs), "l1_tag_ceiling_per_clk_cu": 1.55,
+                    "l2_to_l1_TBps": c["TCP_TCC_READ_REQ_sum"] * 64.0 / secs / 1e12, "l2_to_l1_ceiling_TBps": 17.0,
+                    "past_l2_TBps": c["FETCH_SIZE"] * 1024.0 / secs / 1e12, "past_l2_ceiling_TBps": 4.2}
         else:
             result["roofline"]["traffic_stale"] = info
 
