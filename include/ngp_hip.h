@@ -272,6 +272,12 @@ int ngp_train_mix_backward(const float* grad_out_image, const float* bg, uint32_
 /* mse head: nerf/utils.py:450,480 loss = mean((pred - target)^2), :789 scaler.scale(loss).  loss[0] = the mean, loss[1] = the mean * scale[0] (scale may be
  * NULL: loss[1] = loss[0]); grad_unit [numel] = 2 / numel * (pred - target), the gradient for a unit incoming one.  workspace: ngp_mse_head_workspace() bytes,
  * zero-filled once by the caller, one per stream.  backward: grad_pred = grad_unit * (grad_loss[0] + grad_scaled[0] * scale[0]); either may be NULL. */
+/* mix forward + mse head forward + mse head backward (incoming gradient 1 on the scaled loss) + mix backward in ONE launch, for a caller that runs the backward
+ * right behind the forward: the same values, bit for bit, as the four calls.  It also clears up to three caller buffers (16-byte aligned, multiples of 16 bytes)
+ * that the backward launches after it expect zeroed.  workspace: the mse head's. */
+int ngp_train_head_direct(const float* weights_sum, const float* image, const float* bg, uint32_t bg_rows, float bg_value, const float* target,
+                          const float* scale, uint32_t N, float* out_image, float* loss, float* grad_image, float* grad_weights_sum,
+                          void* const* zero_ptrs, const uint64_t* zero_bytes, uint32_t zero_count, void* workspace, size_t workspace_bytes, void* stream);
 size_t ngp_mse_head_workspace(void);
 int ngp_mse_head_forward(const float* pred, const float* target, uint32_t numel, const float* scale, float* loss, float* grad_unit,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -104,6 +104,97 @@ __global__ __launch_bounds__(TH_BLOCK) void k_mse_head_bwd(const float* __restri
     grad_pred[i] = grad_unit[i] * g;
 }
 
+// ---- the four launches above as ONE, for a caller that runs forward and backward back to back (ngp/train.py's direct step) ----------------------------------
+// Element i = channel i % 3 of ray i / 3: mixed = image + (1 - weights_sum) * bg; d = mixed - target; the loss sums d * d with k_mse_head_fwd's partition and
+// tree (the same bits); grad_image = (2 / numel * d) * scale -- k_mse_head_fwd's grad_unit times k_mse_head_bwd's factor for an incoming gradient of one on
+// the scaled loss --; grad_weights_sum = -(g . bg) by the lane that holds a ray's first channel.  Every workgroup also clears its share of up to three
+// buffers the backward launches that follow expect zeroed (the compositor's two gradient arrays, the header of the field backward's workspace).
+struct th_zero { void* p[3]; uint64_t bytes[3]; };
+
+__global__ __launch_bounds__(TH_BLOCK) void k_train_head_direct(const float* __restrict__ weights_sum, const float* __restrict__ image, const float* __restrict__ bg,
+                                                             uint32_t bg_rows, float bg_value, const float* __restrict__ target, const float* __restrict__ scale,
+                                                             uint32_t N, uint32_t loss_blocks, uint32_t per_block, float* __restrict__ out_image,
+                                                             float* __restrict__ loss, float* __restrict__ grad_image, float* __restrict__ grad_weights_sum,
+                                                             uint32_t* ticket, float* partial, th_zero Z) {
+    __shared__ float lds[TH_BLOCK / 64];
+    __shared__ uint32_t s_last;
+    #pragma unroll
+    for (int z = 0; z < 3; z++) {
+        uint4* q = reinterpret_cast<uint4*>(Z.p[z]);
+        const uint64_t n16 = Z.bytes[z] / 16;
+        for (uint64_t i = (uint64_t)blockIdx.x * TH_BLOCK + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * TH_BLOCK) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (blockIdx.x >= loss_blocks) return;
+    const uint32_t numel = 3u * N;
+    const uint32_t lo = blockIdx.x * per_block;
+    const uint32_t hi = lo + per_block < numel ? lo + per_block : numel;
+    const float unit = 2.0f / (float)numel;
+    const float sc = scale ? scale[0] : 1.0f;
+    float acc = 0.0f;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += TH_BLOCK) {
+        const uint32_t n = i / 3u, c = i - 3u * n;
+        const float rest = 1.0f - weights_sum[n];
+        const float mixed = image[i] + rest * th_bg(bg, bg_rows, bg_value, n, c);
+        out_image[i] = mixed;
+        const float d = mixed - target[i];
+        acc += d * d;
+        const float g = (unit * d) * sc;
+        grad_image[i] = g;
+        if (c == 0) {                                                       // this lane also forms the ray's grad_weights_sum: the other two channels again
+            const float g1 = (unit * ((image[i + 1] + rest * th_bg(bg, bg_rows, bg_value, n, 1)) - target[i + 1])) * sc;
+            const float g2 = (unit * ((image[i + 2] + rest * th_bg(bg, bg_rows, bg_value, n, 2)) - target[i + 2])) * sc;
+            float s = g * th_bg(bg, bg_rows, bg_value, n, 0);
+            s = s + g1 * th_bg(bg, bg_rows, bg_value, n, 1);
+            s = s + g2 * th_bg(bg, bg_rows, bg_value, n, 2);
+            grad_weights_sum[n] = -s;
+        }
+    }
+    const float total = th_block_sum(acc, lds);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = total;
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == loss_blocks - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u || threadIdx.x != 0) return;
+    __threadfence();
+    float s = 0.0f;
+    for (uint32_t b = 0; b < loss_blocks; b++) s += partial[b];
+    const float mean = s / (float)numel;
+    loss[0] = mean;
+    loss[1] = scale ? mean * scale[0] : mean;
+    *ticket = 0u;
+}
+
+extern "C" int ngp_train_head_direct(const float* weights_sum, const float* image, const float* bg, uint32_t bg_rows, float bg_value, const float* target,
+                                     const float* scale, uint32_t N, float* out_image, float* loss, float* grad_image, float* grad_weights_sum,
+                                     void* const* zero_ptrs, const uint64_t* zero_bytes, uint32_t zero_count, void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(N >= 1 && N <= 0x55555555u / 1u, "train_head_direct: 1 .. 2^32 / 3 rays");
+    NGP_REQUIRE(weights_sum && image && target && out_image && loss && grad_image && grad_weights_sum && workspace, "train_head_direct: null pointer");
+    NGP_REQUIRE(bg_rows == 0 || ((bg_rows == 1 || bg_rows == N) && bg), "train_head_direct: bg_rows must be 0 (bg_value), 1 (bg[3]) or N (bg[N,3])");
+    NGP_REQUIRE(zero_count <= 3 && (zero_count == 0 || (zero_ptrs && zero_bytes)), "train_head_direct: at most three buffers to clear");
+    if (workspace_bytes < (size_t)(1 + TH_MAX_BLOCKS) * 4) return ngp_fail(NGP_EWORKSPACE, "train_head_direct: workspace of %zu bytes, %zu needed", workspace_bytes, (size_t)(1 + TH_MAX_BLOCKS) * 4);
+    th_zero Z{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+    uint64_t most = 0;
+    for (uint32_t z = 0; z < zero_count; z++) {
+        NGP_REQUIRE(zero_bytes[z] == 0 || (zero_ptrs[z] && ((uintptr_t)zero_ptrs[z] % 16) == 0 && zero_bytes[z] % 16 == 0), "train_head_direct: buffers to clear must be 16-byte aligned multiples of 16 bytes");
+        Z.p[z] = zero_ptrs[z]; Z.bytes[z] = zero_bytes[z];
+        if (zero_bytes[z] > most) most = zero_bytes[z];
+    }
+    const uint32_t numel = 3u * N;
+    uint32_t loss_blocks = ngp_div_up(numel, TH_SLICE);                    // k_mse_head_fwd's partition: the same sums in the same order
+    if (loss_blocks > TH_MAX_BLOCKS) loss_blocks = TH_MAX_BLOCKS;
+    const uint32_t per_block = ngp_div_up(numel, loss_blocks);
+    uint32_t blocks = ngp_div_up(most, (uint64_t)TH_BLOCK * 16 * 8);       // ~8 16-byte stores per thread of the clearing loop
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < loss_blocks) blocks = loss_blocks;
+    uint32_t* ticket = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_train_head_direct, dim3(blocks), dim3(TH_BLOCK), 0, (hipStream_t)stream, weights_sum, image, bg, bg_rows, bg_value, target, scale, N,
+                       loss_blocks, per_block, out_image, loss, grad_image, grad_weights_sum, ticket, (float*)(ticket + 1), Z);
+    NGP_CHECK_LAUNCH("train_head_direct");
+    return NGP_OK;
+}
+
 extern "C" int ngp_train_mix_forward(const float* weights_sum, const float* depth, const float* image, const float* nears, const float* fars,
                                      const float* bg, uint32_t bg_rows, float bg_value, uint32_t N, float* out_image, float* out_depth, void* stream) {
     if (N == 0) return NGP_OK;

@@ -22,6 +22,7 @@ gradients, so an inf or NaN on one rank is one on all ranks (a replica that skip
 diverge).
 """
 import contextlib
+import ctypes
 
 import torch
 import torch.distributed as dist
@@ -336,12 +337,11 @@ class NGPTrainer:
     @torch.no_grad()
     def _direct_forward_backward(self, ren, field, rays_o, rays_d, target, bg_color, dt_gamma=0, max_steps=1024):
         """`run_cuda`'s training branch (ngp/render.py, nerf/renderer.py:282-321), the loss and the whole backward as straight-line calls of the function
-        bodies the autograd route runs (raymarching._march_rays_train, field._field_train, raymarching._composite_rays_train, render._mix_background,
-        _mse_head): same launches, same order, same values; the gradients end up in `.grad` (or with the exchange, as there).  Returns the loss."""
+        bodies the autograd route runs (raymarching._march_rays_train, field._field_train, raymarching._composite_rays_train; render._mix_background and
+        _mse_head, forward and backward, as the one launch ngp_train_head_direct): same values in the same order; the gradients end up in `.grad` (or with the exchange, as there).  Returns the loss."""
         import raymarching
         from raymarching import raymarching as RM
         from .field import _field_train
-        from .render import _mix_background
         o, d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
         nears, fars = raymarching.near_far_from_aabb(o, d, ren._aabb(), ren.min_near)
         counter = ren.step_counter[ren.local_step % 16]
@@ -355,16 +355,35 @@ class NGPTrainer:
         scale_sigma = ren.density_scale != 1
         c_comp = _Ctx((True, True, False, False))
         weights_sum, depth, image = _body(RM._composite_rays_train.forward)(c_comp, ren.density_scale * sigmas if scale_sigma else sigmas, rgbs, deltas, rays)
-        c_mix = _Ctx()
-        mixed, _ = _mix_background.forward(c_mix, weights_sum, depth, image, nears, fars, bg_color)
-        c_loss = _Ctx()
-        both = _mse_head.forward(c_loss, mixed.view(target.shape), target, self.opt._state_on(mixed.device)[:1])
-        # ---- backward, in the engine's order ----
-        if self._one is None or self._one.device != mixed.device:
-            self._one = torch.ones(1, dtype=torch.float32, device=mixed.device)
-        g_mixed = _mse_head.backward(c_loss, None, self._one)[0]
-        g_ws, _, g_image, _, _, _ = _mix_background.backward(c_mix, g_mixed.view(-1, 3), None)
+        # background mix, loss, and the loss's backward down to the compositor's two incoming gradients in ONE launch (the values of _mix_background and
+        # _mse_head run forward and backward, bit for bit); the same launch clears what the next two backward launches expect zeroed
+        import ngp_hip as _hip
+        L, dev, M, N = _hip.lib(), image.device, xyzs.shape[0], weights_sum.shape[0]
+        mixed = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        both = torch.empty(2, dtype=torch.float32, device=dev)
+        g_image, g_ws = torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)
+        sig_in = c_comp.saved_tensors[0]
+        g_sig, g_rgb = torch.empty_like(sig_in), torch.empty(sig_in.shape[0], 3, dtype=torch.float32, device=dev)
+        work = _hip.workspace(L.ngp_field_train_workspace(M), dev)
+        clear = [(g_sig, g_sig.numel() * 4), (g_rgb, g_rgb.numel() * 4), (work, int(L.ngp_field_train_workspace(0)))]
+        clear = [(t, b) for t, b in clear if b > 0 and t.data_ptr() % 16 == 0 and b % 16 == 0]
+        if len(clear) < 3:                           # (an empty batch, or a size that is not a multiple of 16 bytes: the torch fills)
+            g_sig.zero_(); g_rgb.zero_(); work[:L.ngp_field_train_workspace(0)].zero_()
+            clear = []
+        ws_head = _mse_head._ws.get(dev)
+        if ws_head is None:
+            ws_head = _mse_head._ws[dev] = torch.zeros(int(L.ngp_mse_head_workspace()), dtype=torch.uint8, device=dev)
+        zp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t, _ in clear], *([None] * (3 - len(clear))))
+        zb = (ctypes.c_uint64 * 3)(*[b for _, b in clear], *([0] * (3 - len(clear))))
+        tgt = target.contiguous().view(-1)
+        _hip.check(L.ngp_train_head_direct(_hip.ptr(weights_sum), _hip.ptr(image), None, 0, float(bg_color), _hip.ptr(tgt),
+                                           _hip.ptr(self.opt._state_on(dev)[:1]), N, _hip.ptr(mixed), _hip.ptr(both), _hip.ptr(g_image), _hip.ptr(g_ws),
+                                           ctypes.cast(zp, ctypes.c_void_p), ctypes.cast(zb, ctypes.c_void_p), len(clear), _hip.ptr(ws_head), ws_head.numel(),
+                                           _hip.stream()), "train_head_direct")
+        # ---- the rest of the backward, in the engine's order ----
+        c_comp.cleared_grads = (g_sig, g_rgb)
         g_sig, g_rgb, _, _ = _body(RM._composite_rays_train.backward)(c_comp, g_ws, None, g_image)
+        c_field.cleared_work = work
         if scale_sigma:
             g_sig = g_sig * ren.density_scale
         grads = _body(_field_train.backward)(c_field, g_sig, g_rgb)

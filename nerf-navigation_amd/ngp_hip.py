@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ngp_adam_step": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_train_mix_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_train_mix_backward": (c_int, [c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp]),
+    "ngp_train_head_direct": (c_int, [c_vp, c_vp, c_vp, c_u32, c_f32, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_sz, c_vp]),
     "ngp_mse_head_workspace": (c_sz, []),
     "ngp_mse_head_forward": (c_int, [c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_mse_head_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp]),

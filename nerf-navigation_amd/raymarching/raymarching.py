@@ -188,8 +188,8 @@ class _composite_rays_train(Function):
         grad_image = grad_image.contiguous()
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N = ctx.dims
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
+        # (a caller that runs this body directly may hand in buffers it has already cleared: ngp/train.py's direct step clears them in its loss-head launch)
+        grad_sigmas, grad_rgbs = getattr(ctx, "cleared_grads", None) or (torch.zeros_like(sigmas), torch.zeros_like(rgbs))
         _hip.check(_hip.lib().ngp_composite_rays_train_backward(_hip.ptr(grad_weights_sum), _hip.ptr(grad_image), _hip.ptr(sigmas),
                                                                 _hip.ptr(rgbs), _hip.ptr(deltas), _hip.ptr(rays),
                                                                 _hip.ptr(weights_sum), _hip.ptr(image), M, N,
