@@ -75,8 +75,9 @@ class _field_train(Function):
         sig = torch.empty(M, dtype=torch.float32, device=x.device)
         rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
         saved = _hip.workspace(L.ngp_field_train_saved_bytes(M), x.device)
-        _hip.check(L.ngp_field_train_forward(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb), _hip.ptr(saved),
-                                             saved.numel(), _hip.stream()), "field_train_forward")
+        with _hip.timed("field_train_forward"):
+            _hip.check(L.ngp_field_train_forward(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb), _hip.ptr(saved),
+                                                 saved.numel(), _hip.stream()), "field_train_forward")
         ctx.save_for_backward(x, d, saved, *field._fused["tensors"])
         ctx.fstruct, ctx.field = f, field
         return sig, rgb
@@ -97,9 +98,10 @@ class _field_train(Function):
         if work is None:
             work = _hip.workspace(L.ngp_field_train_workspace(M), x.device)
             work[:L.ngp_field_train_workspace(0)].zero_()
-        _hip.check(L.ngp_field_train_backward(ctypes.byref(ctx.fstruct), _hip.ptr(saved), _hip.ptr(d), M, _hip.ptr(g_sig), _hip.ptr(g_rgb),
-                                              _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), _hip.stream()),
-                   "field_train_backward")
+        with _hip.timed("field_train_backward"):
+            _hip.check(L.ngp_field_train_backward(ctypes.byref(ctx.fstruct), _hip.ptr(saved), _hip.ptr(d), M, _hip.ptr(g_sig), _hip.ptr(g_rgb),
+                                                  _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), _hip.stream()),
+                       "field_train_backward")
         # data-parallel training: the exchange (ngp/train.py GradExchange) takes the gradients as they appear -- the weight bucket now, so that its
         # all-reduce runs underneath the table scatter; the table gradient as the half tensor the scatter writes, pre-divided by the world size
         sink = getattr(field, "grad_sink", None)

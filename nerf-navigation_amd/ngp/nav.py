@@ -111,10 +111,12 @@ class _GraphedPointwise(torch.autograd.Function):
         return sigma
 
     @staticmethod
-    @torch.autograd.function.once_differentiable          # like the reference's encoder backward: no second derivative
     def backward(ctx, grad_sigma):
+        # The reference's rule: the encoder's backward is a native op writing into a fresh tensor, so under create_graph=True the
+        # gradient w.r.t. the points is a CONSTANT (no graph to the points, none to grad_sigma) and no error is raised -- not @once_differentiable,
+        # which would make torch.autograd.functional.hessian (nav/estimator_helpers.py:384) fail where the reference returns a matrix.
         (jac,) = ctx.saved_tensors
-        return grad_sigma.reshape(-1, 1) * jac, None
+        return (grad_sigma.detach().reshape(-1, 1) * jac).detach(), None
 
 
 class GraphedDensity:
@@ -215,7 +217,8 @@ class _NativeField:
 
 class _nav_density(torch.autograd.Function):
     """sigma = trunc_exp(h0(x)) for [M,3] points in one launch; backward to the points in one launch (ngp_nav_density_*).  Like the
-    reference's encoder backward this is a first-order op: no graph is built through the gradient."""
+    reference's encoder backward this is a first-order op whose gradient carries NO graph under create_graph=True: every
+    path from the points to sigma crosses the grid encoder (gridencoder/grid.py:61-87), so the reference's gradient is graph-less too."""
 
     @staticmethod
     def forward(ctx, x, owner):
@@ -233,11 +236,11 @@ class _nav_density(torch.autograd.Function):
         return sigma
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_sigma):
         import ctypes
         import ngp_hip as _hip
         (x,) = ctx.saved_tensors
+        grad_sigma = grad_sigma.detach()
         M = x.shape[0]
         gx = torch.empty_like(x)
         st, prep = ctx.owner.struct()
@@ -248,7 +251,11 @@ class _nav_density(torch.autograd.Function):
 
 
 class _nav_run(torch.autograd.Function):
-    """NeRFRenderer.run(num_steps, upsample_steps = 0, perturb = False) for [N,3] rays: one launch forward, one backward to the rays."""
+    """NeRFRenderer.run(num_steps, upsample_steps = 0, perturb = False) for [N,3] rays: one launch forward, one backward to the rays.
+    Second derivatives (the pose filter's Hessian, nav/estimator_helpers.py:384): in the reference every path from the rays to the image crosses an
+    encoder (xyzs -> grid encoder, dirs -> SH encoder; near / far are computed under no_grad, nerf/renderer.py:140-141), whose backward returns
+    graph-less tensors; so d L / d rays is a constant of the second pass there, and the tensors this backward fills through the C ABI are exactly that.
+    tests/test_gpu_nav_golden.py checks the 12 x 12 Hessian against the executed reference's."""
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, owner, num_steps, bg):
@@ -279,11 +286,11 @@ class _nav_run(torch.autograd.Function):
         return image, depth, ws
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g_image, g_depth, g_ws):
         import ctypes
         import ngp_hip as _hip
         rays_o, rays_d, nears, fars, saved = ctx.saved_tensors
+        g_image, g_depth, g_ws = g_image.detach(), g_depth.detach(), g_ws.detach()
         N = rays_o.shape[0]
         go, gd = torch.empty_like(rays_o), torch.empty_like(rays_d)
         st, prep = ctx.owner.struct()

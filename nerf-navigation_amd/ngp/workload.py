@@ -171,6 +171,22 @@ def make_model(seed=0, bound=BOUND, scene="ring"):
     return dict(embeddings=emb, offsets=offsets, per_level_scale=pls, sigma_weights=sigma_w, color_weights=color_w, bound=bound)
 
 
+def nav_weights(seed=0):
+    """The DEFAULT field's five bias-free Linear matrices (nerf/network.py:33-68: 32-64-16 | 31-64-64-3) hand-set like `make_model`'s FFMLP so that,
+    over `make_model(seed)["embeddings"]`, the field the nav loop queries in float32 (BASELINE config 4) is the same scene: sigma = exp(8.2 occ - 4.1),
+    occ the trilinearly interpolated occupancy feature -- smooth across box faces, so d sigma / d x is informative for the planner.
+    Returns (sigma_layers [64,32],[16,64]; colour_layers [64,31],[64,64],[3,64]) float32."""
+    rng = np.random.default_rng(seed + 1000)
+    f_occ, f_one = 2 * OCC_LEVEL, 2 * ONE_LEVEL + 1
+    w1 = rng.uniform(-0.3, 0.3, size=(64, 32)); w2 = rng.uniform(-0.3, 0.3, size=(16, 64))
+    w1[0] = 0; w1[1] = 0; w1[0, f_occ] = 1.0; w1[1, f_one] = 1.0
+    w2[0] = 0; w2[0, 0] = 8.2; w2[0, 1] = -4.1
+    std = math.sqrt(3 / 64)
+    c = [rng.uniform(-std, std, size=shape) for shape in ((64, 31), (64, 64), (3, 64))]
+    c[2] = c[2] * 6.0                                          # spread the colours over (0, 1) instead of hovering around 0.5
+    return [w1.astype(np.float32), w2.astype(np.float32)], [m.astype(np.float32) for m in c]
+
+
 def intrinsics(H, W, fovx=0.6911):
     """(fx, fy, cx, cy) of a square-pixel pinhole; fovx is nerf_synthetic's camera_angle_x."""
     f = 0.5 * W / math.tan(0.5 * fovx)

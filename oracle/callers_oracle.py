@@ -127,6 +127,64 @@ def sh_encode(d, degree=4):
     return torch.stack(cols, dim=-1)
 
 
+class _GridEncodeFirstOrder(torch.autograd.Function):
+    """_grid_encode (gridencoder/grid.py:19-87) with the reference's DIFFERENTIATION RULE: its backward hands `grad` to a native op that writes
+    into fresh tensors (`grad_inputs = torch.zeros_like(inputs)` :76, `@once_differentiable` commented out :62), so under create_graph=True the
+    gradients w.r.t. inputs and table carry NO graph -- neither back to the inputs nor to `grad`.  torch.autograd.functional.hessian
+    (nav/estimator_helpers.py:384) therefore sees the encoder as a function whose gradient is a constant.  Values = `grid_encode`."""
+
+    @staticmethod
+    def forward(ctx, x, embeddings, offsets, per_level_scale, base_resolution, bound, gridtype, align_corners):
+        ctx.save_for_backward(x, embeddings)
+        ctx.args = (offsets, per_level_scale, base_resolution, bound, gridtype, align_corners)
+        return grid_encode(x.detach(), embeddings.detach(), *ctx.args)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, emb = ctx.saved_tensors
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1]]
+        with torch.enable_grad():
+            xi, ei = x.detach().requires_grad_(need[0]), emb.detach().requires_grad_(need[1])
+            y = grid_encode(xi, ei, *ctx.args)
+            wrt = [t for t, n in zip((xi, ei), need) if n]
+            got = list(torch.autograd.grad(y, wrt, grad.detach(), allow_unused=True)) if wrt else []
+        out = [None, None]
+        for k in (0, 1):
+            if need[k]:
+                g = got.pop(0)
+                out[k] = (torch.zeros_like((x, emb)[k]) if g is None else g).detach()
+        return (out[0], out[1]) + (None,) * 6
+
+
+def grid_encode_first_order(x, embeddings, offsets, per_level_scale, base_resolution=16, bound=1.0, gridtype=0, align_corners=False):
+    """`grid_encode` as the reference's autograd.Function differentiates it: first derivatives only, graph-less (see _GridEncodeFirstOrder)"""
+    return _GridEncodeFirstOrder.apply(x, embeddings, offsets, per_level_scale, base_resolution, bound, gridtype, align_corners)
+
+
+class _SHEncodeFirstOrder(torch.autograd.Function):
+    """_sh_encoder (shencoder/sphere_harmonics.py:14-54): same rule -- `grad_inputs = torch.zeros_like(inputs)` filled by the native op (:49-51)."""
+
+    @staticmethod
+    def forward(ctx, d, degree):
+        ctx.save_for_backward(d)
+        ctx.degree = degree
+        return sh_encode(d.detach(), degree)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (d,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        with torch.enable_grad():
+            di = d.detach().requires_grad_(True)
+            (g,) = torch.autograd.grad(sh_encode(di, ctx.degree), di, grad.detach())
+        return g.detach(), None
+
+
+def sh_encode_first_order(d, degree=4):
+    return _SHEncodeFirstOrder.apply(d, degree)
+
+
 class _TruncExp(torch.autograd.Function):
     """activation.py:5-18"""
 
@@ -150,10 +208,15 @@ class DefaultField:
     """NeRFNetwork of nerf/network.py: sigma net Linear(32,64), Linear(64,16); colour net Linear(31,64), Linear(64,64), Linear(64,3);
     no biases (:45,66).  Parameters are plain leaf tensors so tests read their .grad."""
 
-    def __init__(self, embeddings, offsets, per_level_scale, sigma_weights, color_weights, bound, dtype=torch.float32, ff_layout=False):
+    def __init__(self, embeddings, offsets, per_level_scale, sigma_weights, color_weights, bound, dtype=torch.float32, ff_layout=False,
+                 first_order_encoders=False):
         """ff_layout: the FFMLP variant of nerf/network_ff.py:51-77 -- colour input cat(SH16, geo15, one zero column) = 32 wide (:67-68),
-        colour output 16 wide of which [:3] is used (:72-74); any number of hidden layers in either net."""
+        colour output 16 wide of which [:3] is used (:72-74); any number of hidden layers in either net.
+        first_order_encoders: differentiate the encoders like the reference's autograd.Functions (graph-less gradients, N3) -- needed whenever a
+        caller asks for second derivatives (the pose filter's Hessian); first derivatives are the same either way."""
         self.ff_layout = ff_layout
+        self._grid = grid_encode_first_order if first_order_encoders else grid_encode
+        self._sh = sh_encode_first_order if first_order_encoders else sh_encode
         as_t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype).clone().requires_grad_(True)        # noqa: E731
         self.embeddings = as_t(embeddings)
         self.offsets = [int(v) for v in offsets]
@@ -175,7 +238,7 @@ class DefaultField:
         return h
 
     def density(self, x):                                               # network.py:125-143
-        h = self._mlp(self.sigma_weights, grid_encode(x, self.embeddings, self.offsets, self.per_level_scale, bound=self.bound))
+        h = self._mlp(self.sigma_weights, self._grid(x, self.embeddings, self.offsets, self.per_level_scale, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):          # network.py:163-191
@@ -184,7 +247,7 @@ class DefaultField:
             if not mask.any():
                 return rgbs
             d, geo_feat = d[mask], geo_feat[mask]
-        cin = [sh_encode(d.to(self.dtype)), geo_feat]
+        cin = [self._sh(d.to(self.dtype)), geo_feat]
         if self.ff_layout:
             cin.append(torch.zeros_like(geo_feat[..., :1]))
         h = torch.sigmoid(self._mlp(self.color_weights, torch.cat(cin, dim=-1))[..., :3])

@@ -120,6 +120,9 @@ def _oracle_raymarching():
     return m
 
 
+ENCODER_RULE = {"first_order": False}          # tier4: differentiate the encoders as the reference's autograd.Functions do (graph-less gradients, N3)
+
+
 def _oracle_encoder_modules():
     """modules `gridencoder`, `shencoder`, `ffmlp` for nerf/network*.py and encoding.get_encoder: the reference's class names and constructor
     arguments, oracle arithmetic (float32 on the CPU)"""
@@ -139,8 +142,9 @@ def _oracle_encoder_modules():
             self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim).uniform_(-1e-4, 1e-4))
 
         def forward(self, inputs, bound=1):
-            return CO.grid_encode(inputs.view(-1, self.input_dim), self.embeddings, self.offsets.tolist(), self.per_level_scale, self.base_resolution,
-                                  bound, self.gridtype_id, self.align_corners).view(list(inputs.shape[:-1]) + [self.output_dim])
+            enc = CO.grid_encode_first_order if ENCODER_RULE["first_order"] else CO.grid_encode
+            return enc(inputs.view(-1, self.input_dim), self.embeddings, self.offsets.tolist(), self.per_level_scale, self.base_resolution,
+                       bound, self.gridtype_id, self.align_corners).view(list(inputs.shape[:-1]) + [self.output_dim])
 
     class SHEncoder(nn.Module):                                      # shencoder/sphere_harmonics.py:61-87
         def __init__(self, input_dim=3, degree=4):
@@ -149,7 +153,8 @@ def _oracle_encoder_modules():
 
         def forward(self, inputs, size=1):
             x = inputs / size
-            return CO.sh_encode(x.view(-1, 3), self.degree).view(list(inputs.shape[:-1]) + [self.output_dim])
+            enc = CO.sh_encode_first_order if ENCODER_RULE["first_order"] else CO.sh_encode
+            return enc(x.view(-1, 3), self.degree).view(list(inputs.shape[:-1]) + [self.output_dim])
 
     class FFMLP(nn.Module):                                          # ffmlp/ffmlp.py:99-168: flat weights [hidden,in] + (n-1) [hidden,hidden] + [16,hidden]
         def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu"):
@@ -524,17 +529,146 @@ def tier3_fields():
     return out
 
 
+def nav_network():
+    """the reference's default NeRFNetwork (nerf/network.py) holding the S-ring nav model (ngp.workload.make_model(0) table + nav_weights(0)), eval mode"""
+    import nerf.network as NW
+    assert NW.__file__.startswith(REF)
+    model = W.make_model(0)
+    sw, cw = W.nav_weights(0)
+    net = NW.NeRFNetwork(bound=W.BOUND, cuda_ray=False).eval()
+    with torch.no_grad():
+        net.encoder.embeddings.copy_(torch.from_numpy(model["embeddings"]))
+        for layer, w in zip(list(net.sigma_net) + list(net.color_net), sw + cw):
+            assert tuple(layer.weight.shape) == w.shape
+            layer.weight.copy_(torch.from_numpy(w))
+    return net
+
+
+NAV_ROT = [[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]            # simulate.py:340
+
+
+def nav_planner_cfg(steps=8, nbins=(4, 4, 3)):
+    """simulate.py:266-283 with a shorter horizon and a coarser body (the fixture stays small)"""
+    return {"T_final": 2., "steps": steps, "lr": 0.001, "epochs_init": 1, "fade_out_epoch": 0, "fade_out_sharpness": 10, "epochs_update": 1,
+            "I": torch.eye(3), "g": 10., "mass": 1., "body": np.array([[-0.05, 0.05], [-0.05, 0.05], [-0.02, 0.02]]), "nbins": list(nbins)}
+
+
+def tier4_nav(U):
+    """The two nav/ callers of the hot path, EXECUTED: Planner (nav/quad_plot.py:10-60,120-254) and Estimator.measurement_fn + the Hessian call
+    (nav/estimator_helpers.py:127-170,293-327,384) over simulate.py:340-347's three lambdas on the reference's default NeRFNetwork.
+    cv2 / imageio are empty placeholder modules (nav/estimator_helpers.py:5, nav/agent_helpers.py:5,7 import them; nothing on these paths uses them)."""
+    import nav.estimator_helpers as EH
+    import nav.math_utils as MU
+    import nav.quad_plot as QP
+    assert QP.__file__.startswith(REF) and EH.__file__.startswith(REF)
+    ENCODER_RULE["first_order"] = True
+    net = nav_network()
+    rot = torch.tensor(NAV_ROT)
+    density_fn = lambda x: net.density(x.reshape((-1, 3)) @ rot)["sigma"].reshape(x.shape[:-1])                      # noqa: E731  simulate.py:343
+    out = {}
+
+    # ---- (a) planner: cost of a near-straight trajectory THROUGH the pillar at 180 degrees (NeRF frame (-0.65, 0, 0..0.45) = planner frame (z, x, y)), gradient w.r.t. its parameters
+    start = torch.cat([torch.tensor([0.2, -0.9, -0.05]), torch.zeros(3), MU.vec_to_rot_matrix(torch.tensor([0., 0., 0.])).reshape(-1), torch.zeros(3)])
+    end = torch.cat([torch.tensor([0.25, -0.3, 0.05]), torch.zeros(3), MU.vec_to_rot_matrix(torch.tensor([0., 0., 0.])).reshape(-1), torch.zeros(3)])
+    for tag, cfg, epoch in (("pl", nav_planner_cfg(), 0), ("plf", dict(nav_planner_cfg(steps=10, nbins=(3, 3, 2)), fade_out_epoch=8), 3)):
+        pl = QP.Planner(start, end, cfg, density_fn)
+        pl.epoch = epoch
+        with torch.no_grad():                                        # leave the straight line a little so that no term is degenerate
+            pl.states += torch.from_numpy(np.random.default_rng(41).normal(scale=0.02, size=tuple(pl.states.shape)).astype(np.float32))
+            pl.initial_accel += torch.tensor([0.3, -0.2])
+        per_state, collision = pl.get_state_cost()
+        total = pl.total_cost()
+        total.backward()
+        pts = pl.body_to_world(pl.robot_body).detach()
+        out.update({f"{tag}_start": _np(start), f"{tag}_end": _np(end), f"{tag}_steps": np.int64(cfg["steps"]), f"{tag}_nbins": np.array(cfg["nbins"]),
+                    f"{tag}_epoch": np.int64(epoch), f"{tag}_fade_out_epoch": np.int64(cfg["fade_out_epoch"]),
+                    f"{tag}_states": _np(pl.states), f"{tag}_initial_accel": _np(pl.initial_accel), f"{tag}_robot_body": _np(pl.robot_body),
+                    f"{tag}_points": _np(pts), f"{tag}_sigma": _np(density_fn(pts)), f"{tag}_per_state": _np(per_state), f"{tag}_collision": _np(collision),
+                    f"{tag}_total": _np(total), f"{tag}_grad_states": _np(pl.states.grad), f"{tag}_grad_initial_accel": _np(pl.initial_accel.grad),
+                    f"{tag}_actions": _np(pl.get_actions()), f"{tag}_full_states": _np(pl.get_full_states())})
+    assert float(out["pl_collision"].max()) > 1.0, "the trajectory does not touch the scene"
+
+    # ---- (b) pose filter: measurement_fn's loss, gradient and the 12 x 12 Hessian exactly as estimate_state asks for it (:384)
+    Hh, Wd, steps = 20, 20, 64
+    intr = W.intrinsics(Hh, Wd)
+    get_rays_fn = lambda pose: U.get_rays(pose, intr, Hh, Wd)                                                            # noqa: E731  simulate.py:347
+    render_fn = lambda rays_o, rays_d: net.render(rays_o, rays_d, staged=True, bg_color=1., perturb=False, num_steps=steps, upsample_steps=0)  # noqa: E731  :346
+    rng = np.random.default_rng(42)
+    A = rng.normal(size=(12, 12)).astype(np.float32)
+    sig = torch.from_numpy(np.eye(12, dtype=np.float32) + 0.05 * A @ A.T)
+    cfg = {"dil_iter": 3, "batch_size": 16, "kernel_size": 5, "lrate": 1e-3, "N_iter": 1, "sig0": sig, "Q": torch.eye(12), "render_viz": False, "show_rate": [20, 100]}
+    x_prev = torch.tensor([0.95, -1.1, 0.45, 0.1, -0.05, 0.02, 0.12, -0.2, 2.3, 0.01, 0.02, -0.03])
+    est = EH.Estimator(cfg, None, x_prev.clone(), filter=True, get_rays_fn=get_rays_fn, render_fn=render_fn)
+    x = x_prev + torch.from_numpy(rng.normal(scale=0.02, size=12).astype(np.float32))
+    target = torch.from_numpy(rng.uniform(0, 1, (Hh, Wd, 3)).astype(np.float32))
+    batch = np.stack([rng.integers(0, Hh, 16), rng.integers(0, Wd, 16)], axis=-1)
+    xs = x.clone().requires_grad_(True)
+    loss = est.measurement_fn(xs, x_prev, sig, target, batch)
+    loss.backward()
+    hess = torch.autograd.functional.hessian(lambda s: est.measurement_fn(s, x_prev.clone().detach(), sig, target, batch), x.clone().detach())
+    with torch.no_grad():
+        rgb_loss = loss - MU.mahalanobis(x, x_prev, sig)
+        view = est.render_from_pose(torch.cat([torch.cat([MU.vec_to_rot_matrix(x[6:9]), x[:3, None]], dim=1), torch.tensor([[0., 0., 0., 1.]])]))
+    inv = torch.inverse(sig)
+    out.update(mf_state=_np(x), mf_start=_np(x_prev), mf_sig=_np(sig), mf_target=_np(target), mf_batch=batch.astype(np.int64), mf_HW=np.array([Hh, Wd]),
+               mf_intrinsics=intr, mf_num_steps=np.int64(steps), mf_loss=_np(loss), mf_rgb_loss=_np(rgb_loss), mf_grad=_np(xs.grad), mf_hessian=_np(hess),
+               mf_hessian_process=_np(inv + inv.T), mf_view=_np(view))
+    rgb_part = out["mf_hessian"] - out["mf_hessian_process"]
+    assert np.abs(rgb_part[6:9, 6:9]).max() > 1e-4, "the rays do not see the scene: the image term of the Hessian vanishes"
+    ENCODER_RULE["first_order"] = False
+    return out
+
+
+def tier5_composite(R):
+    """SURVEY 8c relation 1 with the reference's side EXECUTED: what NeRFRenderer.run (nerf/renderer.py:206-230) feeds its own torch compositing --
+    the exponent -delta * density_scale * sigma (:208, read off `torch.exp`), the colours (:218) -- and what it returns, so that the native
+    compositor (composite_rays_train_forward) can be checked on the same numbers."""
+    model, field = oracle_field()
+    ren = make_renderer(R, field, bound=W.BOUND, cuda_ray=False, min_near=0.2, density_thresh=10).eval()
+    ro, rd = run_rays()
+    seen = {}
+    orig_exp, orig_color = torch.exp, ren.color
+
+    def exp_spy(x, *a, **k):
+        if x.dim() == 2 and "exponent" not in seen:
+            seen["exponent"] = x.detach().clone()
+        return orig_exp(x, *a, **k)
+
+    def color_spy(x, d, mask=None, **kw):
+        rgbs = orig_color(x, d, mask=mask, **kw)
+        seen["rgbs"], seen["mask"] = rgbs.detach().clone(), mask.detach().clone()
+        return rgbs
+
+    torch.exp, ren.color = exp_spy, color_spy
+    try:
+        with torch.no_grad():
+            res = ren.run(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], bg_color=1.0, num_steps=64, upsample_steps=0)
+    finally:
+        torch.exp = orig_exp
+    N = ro.shape[0]
+    assert seen["exponent"].shape == (N, 64) and seen["rgbs"].shape == (N * 64, 3)
+    return {"rays_o": ro, "rays_d": rd, "exponent": _np(seen["exponent"]), "rgbs": _np(seen["rgbs"]).reshape(N, 64, 3), "mask": _np(seen["mask"]).reshape(N, 64),
+            "image": _np(res["image"][0]), "weights_sum": _np(res["weights_sum"]), "depth": _np(res["depth"][0])}
+
+
+ONLY = set(sys.argv[1:])                       # e.g. `... make_callers_golden.py callers_nav` regenerates that file alone
+
+
 def main():
     U, R, P = import_reference()
     torch.set_num_threads(8)
     O.set_threads(8)
     for name, fn in (("callers_tier1", lambda: tier1(U, R, P)), ("callers_run", lambda: tier2_run(R)),
-                     ("callers_run_cuda", lambda: tier2_run_cuda(R)), ("callers_grid", lambda: tier2_grid(R)), ("callers_fields", tier3_fields)):
+                     ("callers_run_cuda", lambda: tier2_run_cuda(R)), ("callers_grid", lambda: tier2_grid(R)), ("callers_fields", tier3_fields),
+                     ("callers_nav", lambda: tier4_nav(U)), ("callers_composite", lambda: tier5_composite(R))):
+        if ONLY and name not in ONLY:
+            continue
         data = fn()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)
         print(f"{name}: {len(data)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
-    assert not os.path.exists(os.path.join(REF, "nerf", "__pycache__")), "bytecode was written into the reference tree"
+    for sub in ("nerf", "nav"):
+        assert not os.path.exists(os.path.join(REF, sub, "__pycache__")), "bytecode was written into the reference tree"
 
 
 if __name__ == "__main__":

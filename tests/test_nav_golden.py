@@ -1,0 +1,151 @@
+"""SURVEY 8a N1-N3 and 8f-4 pinned by the reference's OWN nav/ Python: tests/golden/callers_nav.npz was produced by executing
+Planner (nav/quad_plot.py) and Estimator.measurement_fn + torch.autograd.functional.hessian (nav/estimator_helpers.py:293-327,384) over
+simulate.py:340-347's lambdas on the reference's default NeRFNetwork (tests/golden/make_callers_golden.py: tier4_nav).  Here, without a GPU:
+
+  * the restated callers (oracle/nav_oracle.py) over the oracle's field reproduce the fixture -- cost, gradient, Hessian -- so the restatement
+    the GPU tests feed the HIP queries through is the reference's;
+  * the oracle's encoders carry the reference's differentiation rule (graph-less first derivatives, `callers_oracle.grid_encode_first_order`):
+    with plain differentiable encoders the Hessian is a DIFFERENT matrix, and the test says so;
+  * tests/golden/callers_composite.npz: what the executed `run()` fed its torch compositing, through the oracle's native compositor (8c relation 1).
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+importlib.import_module("nerf-navigation_amd")
+from ngp import nav  # noqa: E402
+from ngp import workload as W  # noqa: E402
+from oracle import callers_oracle as CO  # noqa: E402
+from oracle import nav_oracle as NO  # noqa: E402
+from oracle import ngp_oracle as O  # noqa: E402
+
+import _nav_cases as NC  # noqa: E402
+
+
+def oracle_nav_field(first_order=True):
+    model = W.make_model(0)
+    sw, cw = W.nav_weights(0)
+    f = CO.DefaultField(model["embeddings"], model["offsets"], model["per_level_scale"], sw, cw, model["bound"], first_order_encoders=first_order)
+    for p in f.parameters():
+        p.requires_grad_(False)                                     # values and input gradients do not depend on it; skips the 50 MB table gradient
+    return f
+
+
+@pytest.fixture(scope="module")
+def field():
+    return oracle_nav_field()
+
+
+def oracle_queries(field, g):
+    rot = torch.tensor(nav.ROT)
+    H, Wd = (int(v) for v in g["mf_HW"])
+    density_fn = lambda x: field.density(x.reshape(-1, 3) @ rot)["sigma"].reshape(x.shape[:-1])                      # noqa: E731
+    get_rays_fn = lambda pose: nav.get_rays(pose, g["mf_intrinsics"], H, Wd)                                        # noqa: E731  (bit-exact vs nerf/utils.py: test_callers_golden)
+
+    def render_fn(rays_o, rays_d):
+        res = CO.run(field, rays_o[0], rays_d[0], W.BOUND, num_steps=int(g["mf_num_steps"]), upsample_steps=0, bg_color=1.0)
+        return {"image": res["image"][None], "depth": res["depth"][None]}
+    return density_fn, get_rays_fn, render_fn
+
+
+@pytest.mark.parametrize("tag", ["pl", "plf"])
+def test_planner_cost_and_gradient_against_executed_planner(field, tag):
+    """Planner.get_state_cost / total_cost().backward() (nav/quad_plot.py:224-254): same torch CPU operations -> 1e-6 relative (the kinematics are
+    reordered nowhere; the margin is for the body-point matmul's blocking)"""
+    g = NC.gold()
+    density_fn, _, _ = oracle_queries(field, g)
+    res = NC.planner_case(g, tag, density_fn)
+    np.testing.assert_allclose(res["points"].detach().numpy(), g[f"{tag}_points"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(density_fn(torch.from_numpy(g[f"{tag}_points"])).numpy(), g[f"{tag}_sigma"], rtol=1e-6)
+    np.testing.assert_allclose(res["per_state"].detach().numpy(), g[f"{tag}_per_state"], rtol=1e-5)
+    np.testing.assert_allclose(res["collision"].detach().numpy(), g[f"{tag}_collision"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(res["total"]), float(g[f"{tag}_total"]), rtol=1e-6)
+    assert NC.rel(res["grad_states"].numpy(), g[f"{tag}_grad_states"]) < 1e-5
+    assert NC.rel(res["grad_initial_accel"].numpy(), g[f"{tag}_grad_initial_accel"]) < 1e-5
+
+
+def test_planner_kinematics_against_executed_planner():
+    """calc_everything through get_actions / get_full_states (nav/quad_plot.py:120-207)"""
+    g = NC.gold()
+    t = lambda k: torch.from_numpy(g[f"pl_{k}"])                                # noqa: E731
+    pos, vel, acc, rot, omega, alpha, actions = NO.planner_kinematics(t("states"), t("initial_accel"), t("start"), t("end"), NC.planner_cfg(g, "pl"))
+    np.testing.assert_allclose(actions.numpy(), g["pl_actions"], rtol=1e-6, atol=1e-6)
+    full = torch.cat([pos, vel, rot.reshape(-1, 9), omega], dim=-1)
+    np.testing.assert_allclose(full.numpy(), g["pl_full_states"], rtol=1e-6, atol=1e-6)
+    body = NO.robot_body([[-0.05, 0.05], [-0.05, 0.05], [-0.02, 0.02]], g["pl_nbins"])
+    np.testing.assert_array_equal(body.numpy(), g["pl_robot_body"])
+    init = NO.planner_initial_states(t("start"), t("end"), int(g["pl_steps"]))
+    assert init.shape == g["pl_states"].shape and np.max(np.abs(init.numpy() - g["pl_states"])) < 0.1        # the generator perturbed the straight line by N(0, 0.02)
+
+
+def test_measurement_fn_loss_gradient_hessian_against_executed_estimator(field):
+    """Estimator.measurement_fn and the Hessian call of estimate_state (nav/estimator_helpers.py:293-327,384).  N3: the image term of the Hessian is
+    sum_k g_k d2 rays_k / d state2 with g = dL/drays a CONSTANT, because every path from the rays to the image crosses an encoder whose backward is
+    graph-less; it lives in the rotation block [6:9, 6:9] only (the translation enters the rays linearly)."""
+    g = NC.gold()
+    _, get_rays_fn, render_fn = oracle_queries(field, g)
+    res = NC.filter_case(g, get_rays_fn, render_fn)
+    np.testing.assert_allclose(float(res["loss"]), float(g["mf_loss"]), rtol=1e-6)
+    assert NC.rel(res["grad"].numpy(), g["mf_grad"]) < 1e-5
+    H = res["hessian"].numpy()
+    assert H.shape == (12, 12)
+    assert np.max(np.abs(H - g["mf_hessian"])) < 1e-5 * np.abs(g["mf_hessian"]).max()
+    image_term = g["mf_hessian"] - g["mf_hessian_process"]
+    outside = np.ones((12, 12), bool); outside[6:9, 6:9] = False
+    assert np.abs(image_term[outside]).max() < 1e-6 and np.abs(image_term[6:9, 6:9]).max() > 0.1
+    assert NC.rel((H - g["mf_hessian_process"])[6:9, 6:9], image_term[6:9, 6:9]) < 1e-4
+
+
+def test_fully_differentiable_encoders_give_a_different_hessian():
+    """the rule is not cosmetic: an oracle whose encoders are ordinary differentiable torch (second derivatives through the trilinear weights and the
+    MLP) returns another matrix than the reference's estimator computes"""
+    g = NC.gold()
+    _, get_rays_fn, render_fn = oracle_queries(oracle_nav_field(first_order=False), g)
+    res = NC.filter_case(g, get_rays_fn, render_fn)
+    np.testing.assert_allclose(float(res["loss"]), float(g["mf_loss"]), rtol=1e-6)            # values and first derivatives agree ...
+    assert NC.rel(res["grad"].numpy(), g["mf_grad"]) < 1e-5
+    image_term = (res["hessian"].numpy() - g["mf_hessian_process"])
+    assert NC.rel(image_term, g["mf_hessian"] - g["mf_hessian_process"]) > 0.05               # ... the Hessian does not
+
+
+def test_render_from_pose_view(field):
+    """Estimator.render_from_pose (nav/estimator_helpers.py:329-345): the full 20 x 20 view at the filter's state"""
+    g = NC.gold()
+    _, get_rays_fn, render_fn = oracle_queries(field, g)
+    with torch.no_grad():
+        rays = get_rays_fn(NO.camera_pose_from_state(torch.from_numpy(g["mf_state"])).reshape(1, 4, 4))
+        img = render_fn(rays["rays_o"], rays["rays_d"])["image"][0]
+    np.testing.assert_allclose(img.numpy(), g["mf_view"], rtol=0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# SURVEY 8c relation 1 with the reference's side executed
+# ------------------------------------------------------------------------------------------------------------------------
+def composite_inputs(c):
+    """the compositor's operands from what run() computed: sigma * delta = -exponent (delta := 1), colours as run() masked them, one ray = T samples"""
+    N, T = c["exponent"].shape
+    sigmas = (-c["exponent"]).reshape(-1).astype(np.float32)
+    deltas = np.ones((N * T, 2), np.float32)
+    rays = np.stack([np.arange(N), np.arange(N) * T, np.full(N, T)], axis=1).astype(np.int32)
+    return sigmas, c["rgbs"].reshape(-1, 3).astype(np.float32), deltas, rays
+
+
+def composite_check(c, ws, image):
+    """run() (nerf/renderer.py:206-230) composites every sample with `+1e-15` in the transmittance; the native compositor stops once T < 1e-4
+    (raymarching.cu:559-562).  Rays that never get there: same sums up to float32 order (2e-6); the others: within the dropped tail, 1e-4."""
+    open_rays = c["weights_sum"] < 1 - 2e-4
+    assert open_rays.sum() > 50 and (~open_rays).sum() > 10
+    mixed = image + (1 - ws)[:, None]                                            # run()'s background mix with bg_color = 1 (:228)
+    assert np.max(np.abs(ws[open_rays] - c["weights_sum"][open_rays])) < 2e-6
+    assert np.max(np.abs(mixed[open_rays] - c["image"][open_rays])) < 2e-6
+    assert np.max(np.abs(ws - c["weights_sum"])) < 1.01e-4 and np.max(np.abs(mixed - c["image"])) < 1.01e-4
+
+
+def test_oracle_compositor_on_the_executed_run_operands():
+    c = np.load(os.path.join(NC.GOLD, "callers_composite.npz"))
+    sigmas, rgbs, deltas, rays = composite_inputs(c)
+    ws, depth, image = O.composite_rays_train_forward(sigmas, rgbs, deltas, rays)
+    composite_check(c, ws, image)
