@@ -3,8 +3,10 @@
 ("S-ring", SURVEY.md 8d / BASELINE config 2) through the fused gfx950 path (csrc/render_fused.hip).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-one rank per GPU.  A step = one frame = ONE kernel launch over 640,000 rays already resident in HBM.  Rays shard
+N > 1 runs one rank per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or -- `python bench.py --gpus N` with WORLD_SIZE unset -- this process
+starts them itself (`launch_ranks`: a child `torch.distributed.run --standalone`-style launch on 127.0.0.1, BEFORE anything here touches a GPU),
+relays rank 0's one JSON line and exits with the children's status.  A step = one frame = ONE kernel launch over 640,000 rays already resident in HBM.  Rays shard
 embarrassingly: every rank renders its own stream of camera poses with a replica of the model (25 MB half table +
 36 KB of weights + 0.5 MB bitfield) and there is no collective on the data path -> weak scaling; the only
 collectives are the timing barrier and the reduction of the counters.
@@ -223,11 +225,48 @@ def fit_model(args, dev, W, teacher):
     student = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
     tr = NGPTrainer(student, lr=1e-2, iters=args.fit_steps, fp16=True, steps_per_epoch=len(pool))       # 24 views = one epoch: the weight average follows
     gen = torch.Generator(device=dev).manual_seed(1)
-    t0 = time.perf_counter()
-    for k in range(args.fit_steps):
+
+    def step(k):
         to, td, tc = pool[k % len(pool)]
         idx = torch.randint(0, res * res, (n_rays,), device=dev, generator=gen)
-        loss = tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=1024)
+        return tr.step(to[:, idx], td[:, idx], tc[:, idx], bg_color=1, max_steps=1024)
+
+    # The LAST `train_steps` steps of the fit are the `train` block of the line (BASELINE config 3 in its steady state: the occupancy grid has
+    # converged, a step marches ~0.6 M points): wall time between two synchronisations, and the field's and the table scatter's launches between
+    # HIP events on the launch stream (ngp_hip.timed).  The same 2,000 steps as without the block: nothing is added to the fit.
+    import ngp_hip
+    tail = 0 if args.no_train_block else max(0, min(int(args.train_steps), args.fit_steps // 2))
+    t0 = time.perf_counter()
+    for k in range(args.fit_steps - tail):
+        loss = step(k)
+    train = None
+    if tail:
+        ngp_hip.TIMERS = {}
+        with no_gc_pauses():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.fit_steps - tail, args.fit_steps):
+                loss = step(k)
+            queued = time.perf_counter() - t1
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t1
+        timers = {name: ngp_hip.timer_ms(name)[0] for name in ("field_train_forward", "field_train_backward", "grid_encode_backward", "adam_step")}
+        ngp_hip.TIMERS = None
+        n = min(16, student.local_step)
+        points = float(student.step_counter[:n, 0].float().mean().item())
+
+        def roof(kernel, ms):
+            if not ms:
+                return None
+            a = SCATTER_BYTES_PER_POINT * points / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "avg_launch_ms": ms,
+                    "algorithmic_bytes_per_point": SCATTER_BYTES_PER_POINT, "points_per_launch": points}
+        train = {"what": f"the last {tail} of the {args.fit_steps} fit steps (4,096 rays per step, FFMLP field under autocast, native Adam + GradScaler, grid refresh every 16 steps: "
+                         "BASELINE config 3, steady state)", "steps": tail, "ms_per_step": 1e3 * wall / tail, "rays_per_s": n_rays * tail / wall,
+                 "points_per_step": points, "host_queue_ms_per_step": 1e3 * queued / tail,
+                 "forward_roofline": roof("k_field_train_forward (gather 512 B per point + both networks)", timers["field_train_forward"]),
+                 "scatter_roofline": roof("k_gs_bin + k_gs_accumulate (binned table-gradient scatter)", timers["grid_encode_backward"]),
+                 "field_backward_ms": timers["field_train_backward"], "optimizer_ms": timers["adam_step"]}
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     student.eval()
@@ -242,7 +281,7 @@ def fit_model(args, dev, W, teacher):
     with torch.no_grad():
         img = student.render_fused(to, td, bg_color=1, image_width=res)["image"]
         psnr = float(-10 * torch.log10(torch.mean((img - tc) ** 2)))
-    return student, {"steps": args.fit_steps, "seconds": seconds, "final_loss": float(loss), "psnr_vs_teacher_db": psnr,
+    return student, train, {"steps": args.fit_steps, "seconds": seconds, "final_loss": float(loss), "psnr_vs_teacher_db": psnr,
                      "weights": f"exponential moving average (decay 0.95, {tr.ema.num_updates} epoch updates), as the reference evaluates", "psnr_live_weights_db": live,
                      "occupied_cells": int(torch.count_nonzero(student.density_grid > min(student.mean_density, 10.0)))}
 
@@ -257,7 +296,7 @@ def fitted_block(args, dev, W, teacher, rays, Wd):
     untimed fit, then --fit-frames timed 800x800 launches with HIP events -- plus the north_star's PSNR criterion on a <= 200^2 view:
     psnr_delta_db = PSNR(HIP render of the student, teacher) - PSNR(CPU-oracle render of the same student, teacher)."""
     from oracle import ngp_oracle as O, render_oracle as R
-    student, fit = fit_model(args, dev, W, teacher)
+    student, train, fit = fit_model(args, dev, W, teacher)
     N = rays[0][0].shape[1]
     for k in range(5):
         student.render_fused(*rays[k % len(rays)], dt_gamma=0, bg_color=1, max_steps=1024, image_width=Wd)
@@ -277,7 +316,7 @@ def fitted_block(args, dev, W, teacher, rays, Wd):
     kernel_s = 1e-3 * float(np.mean([a.elapsed_time(b) for a, b in ev]))
     per_launch = samples / args.fit_frames
     achieved = GATHER_BYTES_PER_SAMPLE * per_launch / kernel_s / 1e9
-    block = {"model": MODEL_NAMES["trained"], "fit": fit, "frames": args.fit_frames, "value": samples / elapsed, "unit": "ray-samples/s",
+    block = {"model": MODEL_NAMES["trained"], "fit": fit, "train": train, "frames": args.fit_frames, "value": samples / elapsed, "unit": "ray-samples/s",
              "ms_per_step": 1e3 * elapsed / args.fit_frames, "fps": args.fit_frames / elapsed, "samples_per_ray": per_launch / N,
              "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                           "kernel": "k_render_frame_multi", "avg_launch_ms": 1e3 * kernel_s}}
@@ -304,6 +343,124 @@ def fitted_block(args, dev, W, teacher, rays, Wd):
                       "max_abs_vs_oracle": float(np.max(np.abs(hip - ref["image"]))), "oracle_seconds": cpu_s, "oracle_ray_samples": ref["samples"],
                       "criterion": "north_star: PSNR within 0.1 dB of the CPU path", "criterion_met": bool(abs(p_hip - p_cpu) < 0.1)})
     return block
+
+
+def nav_block(args, dev, W):
+    """BASELINE config 4 on the fused float32 kernels (csrc/nav_field.hip, ngp.nav.NativeNavQueries) over the default field holding the S-ring scene:
+    (iii) one pose-filter iteration = run() on 1,024 rays x 512 steps + backward to the rays (simulate.py:203-205, nav/estimator_helpers.py:293-327);
+    (ii) the planner's query = density + gradient on [20, 500, 3] body points (nav/quad_plot.py:224-250), as one hipGraph replay; (i) the A* occupancy
+    query on 100^3 points (nav/quad_plot.py:65-79).  Roofline: 1,024 B of float32 gather per sample against HBM, the forward and the
+    (re-gathering) backward launch each event-timed on the launch stream."""
+    import ngp_hip
+    from ngp import nav
+    from ngp.field import NGPField
+    from ngp.render import NGPRenderer
+    model = W.make_model(0)
+    sw, cw = W.nav_weights(0)
+    field = NGPField(bound=W.BOUND).to(dev)
+    with torch.no_grad():
+        field.encoder.embeddings.copy_(torch.from_numpy(model["embeddings"]))
+        for layer, w in zip(list(field.sigma_net) + list(field.color_net), sw + cw):
+            layer.weight.copy_(torch.from_numpy(w))
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=False).to(dev).eval()
+    rays_n, steps_n = 1024, 512
+    q = nav.NativeNavQueries(ren, W.intrinsics(32, 32), 32, 32, num_steps=steps_n)
+    o, d = W.get_rays(W.orbit_pose(1), W.intrinsics(32, 32), 32, 32)
+    o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+
+    def filter_iteration():
+        ro, rd = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        q.render_fn(ro, rd)["image"].sum().backward()
+
+    pts = (torch.rand(20, 500, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 2 - 1)
+    graphed = nav.GraphedDensity(q, n_points=10000)
+
+    def planner_query():
+        p = pts.clone().requires_grad_(True)
+        graphed(p).sum().backward()
+
+    lin = torch.linspace(-1, 1, 100, device=dev)
+    lattice = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), dim=-1)
+
+    def astar_query():
+        with torch.no_grad():
+            q.density_fn(lattice)
+
+    def timeit(fn, n):
+        for _ in range(3):
+            fn()
+        with no_gc_pauses():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
+    n = int(args.nav_iters)
+    planner_ms, astar_ms = timeit(planner_query, 4 * n), timeit(astar_query, n)
+    ngp_hip.TIMERS = {}
+    filter_ms = timeit(filter_iteration, n)
+    fwd_ms, bwd_ms = ngp_hip.timer_ms("nav_run_forward")[0], ngp_hip.timer_ms("nav_run_backward")[0]
+    ngp_hip.TIMERS = None
+    samples = rays_n * steps_n
+
+    def roof(kernel, ms):
+        a = 1024.0 * samples / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "avg_launch_ms": ms,
+                "algorithmic_bytes_per_sample": 1024, "samples_per_launch": samples}
+    return {"what": "BASELINE config 4 (nav loop queries, float32, default field holding the S-ring scene) on the fused kernels of csrc/nav_field.hip",
+            "filter_iteration_ms": filter_ms, "filter_iteration": f"run() {rays_n} rays x {steps_n} steps + backward to the rays", "iterations": n,
+            "filter_samples_per_s": samples / (filter_ms * 1e-3),
+            "planner_query_ms": planner_ms, "planner_query": "density + gradient on 10,000 body points, one hipGraph replay of the level-parallel op chain",
+            "astar_query_ms": astar_ms, "astar_query": "density on the 100^3 lattice, no gradient (k_nav_density_fwd)",
+            "forward_roofline": roof("k_nav_run_fwd", fwd_ms), "backward_roofline": roof("k_nav_run_bwd (recomputes the gather)", bwd_ms)}
+
+
+def drop_in_block(args, ren, rays, N):
+    """The loop an UNMODIFIED nerf/renderer.py:325-374 runs per frame through the drop-in packages (march_rays -> field -> composite_rays -> compaction,
+    one host synchronisation per iteration as there): the path north_star means by "call them unchanged".  800x800, the same rays as the headline."""
+    def frame(k):
+        o, d = rays[k % len(rays)]
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return ren.run_cuda(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024)
+    for k in range(2):
+        frame(k)
+    n = int(args.drop_in_frames)
+    with no_gc_pauses():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            frame(k)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / n
+    return {"what": "run_cuda as an unmodified renderer runs it (nerf/renderer.py:325-374) over the drop-in ops, FFMLP field under autocast, same frames as the headline",
+            "frames": n, "ms_per_frame": 1e3 * sec, "fps": 1.0 / sec, "rays_per_frame": N}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process group (torch.distributed.run on the loopback), relay
+    rank 0's JSON line, exit with the children's status.  Runs before this process has made any GPU call (importing torch does not initialise the
+    device) and never replaces the process (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    print(lines[0])
+    sys.exit(0)
 
 
 def main():
@@ -335,7 +492,16 @@ def main():
     ap.add_argument("--settle", type=int, default=1460, help="train mode: untimed steps between the warm-up phase and the steady-state phase")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render = the headline metric; train = secondary: training steps (configs 3 / 5), 4096 rays per step per GPU")
+    ap.add_argument("--train-steps", type=int, default=64, help="`train` block: the last this-many steps of the fit are timed (0 / --no-train-block = skip)")
+    ap.add_argument("--no-train-block", action="store_true")
+    ap.add_argument("--nav-iters", type=int, default=50, help="`nav` block: timed pose-filter iterations (BASELINE config 4)")
+    ap.add_argument("--no-nav-block", action="store_true")
+    ap.add_argument("--drop-in-frames", type=int, default=5, help="`drop_in` block: timed 800x800 frames of the unchanged-caller loop")
+    ap.add_argument("--no-drop-in-block", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -379,7 +545,7 @@ def main():
 
     fit = None
     if args.model == "trained":
-        ren, fit = fit_model(args, dev, W, ren)                  # untimed: the bench renders the fitted model
+        ren, _, fit = fit_model(args, dev, W, ren)               # untimed: the bench renders the fitted model
         model = None
 
     H = Wd = args.res
@@ -586,6 +752,12 @@ def main():
         result["fit"] = fit
     if args.model == "handset" and args.path == "fused" and world == 1 and not strong and not args.no_fit:
         result["fitted"] = fitted_block(args, dev, W, ren, rays, Wd)
+        result["train"] = result["fitted"].pop("train")      # config 3's steady state = the last steps of that fit, timed (None with --no-train-block)
+    default_line = args.model == "handset" and args.path == "fused" and world == 1 and not strong
+    if default_line and not args.no_drop_in_block:
+        result["drop_in"] = drop_in_block(args, ren, rays, N)
+    if default_line and not args.no_nav_block and args.workload == "ring":
+        result["nav"] = nav_block(args, dev, W)
     if not args.no_cpu and world == 1:
         from oracle import ngp_oracle as O, render_oracle as R
         O.build()

@@ -687,7 +687,7 @@ extern "C" int ngp_grid_encode_backward_inputs(const void* grad, const float* in
 // half of a training step.  Here every contribution is summed ON CHIP instead:
 //   k_gs_bin         one 1,024-thread workgroup per (1,024 consecutive samples, level): the same arithmetic and the same wave-level run
 //                    aggregation as k_grid_backward, but a contribution becomes a 6-byte entry (row inside its slice: u16, value: half2)
-//                    that is counting-sorted by SLICE (a range of 16,384 or 4,096 table rows) in LDS and written out as one contiguous,
+//                    that is counting-sorted by SLICE (about 64 per level: 8,192 table rows of a hashed level down to 512 of the coarsest) in LDS and written out as one contiguous,
 //                    slice-ordered region plus a directory of slice offsets.  Plain coalesced stores, no atomics, no capacity guess:
 //                    a region has room for all 8,192 possible entries.
 //   k_gs_accumulate  persistent workgroups draw slices from a ticket counter; a slice's accumulators (<= 128 KiB) live in LDS as 64-BIT
@@ -702,7 +702,7 @@ extern "C" int ngp_grid_encode_backward_inputs(const void* grad, const float* in
 // entries is exact (the reference and k_grid_backward add in half, in arbitrary order), rounded once on output.
 // Algorithmic bytes per point: 512 B of contributions (16 levels x 8 corners x 2 features x 2 B); traffic: 6 B per entry written and
 // read once (~58 entries per point on a training batch: runs merge on the coarse levels only) + 76 B per sample read + the table written once.
-// Measured (profiles/r15_train, 1.8 M points): k_gs_bin 0.71 + k_gs_accumulate 0.65 ms per step against 2.68 ms for k_grid_backward.
+// Measured (profiles/r15_train_summary.md, 1.80 M points): k_gs_bin 0.43 + k_gs_accumulate 0.39 ms per step against 2.68 ms for k_grid_backward.
 // =====================================================================================================================================
 static constexpr uint32_t GS_CHUNK = 1024;            // samples per region = threads per k_gs_bin workgroup
 static constexpr uint32_t GS_REGION = GS_CHUNK * 8;   // entries a region can hold (every corner of every sample)
@@ -784,7 +784,8 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
 
     // runs of consecutive lanes in the same cell (consecutive samples of a ray): summed across the run, the last lane emits
     const int lane = (int)(tid & 63u);
-    // (four ds_bpermute per wave; DPP wave_shr:1 does not carry across the rows of 16 lanes on this chip: runs were cut at lanes 16 / 32 / 48)
+    // (run DETECTION looks one lane down with __shfl_up = ds_bpermute, four per wave: DPP wave_shr:1 does not carry across the rows of 16 lanes on this
+    // chip and cut the runs at lanes 16 / 32 / 48.  The run SUMS below are DPP only.)
     bool same = valid && lane > 0 && __shfl_up((int)valid, 1, 64) != 0;
     #pragma unroll
     for (uint32_t d = 0; d < D; d++) same = (__shfl_up(pg[d], 1, 64) == pg[d]) && same;
@@ -971,9 +972,9 @@ __global__ __launch_bounds__(1024) void k_gs_accumulate(const uint32_t* __restri
         OUT_T* dst = out + ((size_t)(uint32_t)offsets[level] + row0) * 2;
         const bool poison = s_poison != 0u;            // an inf / NaN contribution (loss-scale overflow): the slice reports NaN, the step is skipped
         for (uint32_t k = tid; k < nrows * 2; k += 1024) {
-            double v = (double)(long long)s_acc[k] * (1.0 / 16777216.0) * (double)out_scale;   // exact sum, one rounding on output
+            double v = (double)(long long)s_acc[k] * (1.0 / 16777216.0) * (double)out_scale;   // exact sum ...
             if (add_to_out) v += (double)(float)dst[k];
-            dst[k] = poison ? (OUT_T)__builtin_nanf("") : (OUT_T)(float)v;
+            dst[k] = poison ? (OUT_T)__builtin_nanf("") : (OUT_T)v;                            // ... ONE rounding on output: double -> float, or double -> half directly
         }
     }
 }
@@ -999,19 +1000,23 @@ static int gs_run(const char* who, const void* grad, const float* inputs, const 
     ge_levels lv;
     ge_fill_levels(lv, L, S, H);
     char* base = (char*)workspace;
-    static bool lds_ok = false;
     const size_t lds = (size_t)GS_SLICE_ROWS * 2 * sizeof(unsigned long long);
-    if (!lds_ok) {
-        if (hipFuncSetAttribute((const void*)k_gs_accumulate<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_gs_accumulate<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ngp_fail(NGP_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
-        lds_ok = true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return ngp_fail(NGP_ELAUNCH, "%s: no current device", who);
+    {   // the raised dynamic-LDS limit is a per-DEVICE function attribute: set once on every device this process scatters on (one process may drive several)
+        static std::atomic<unsigned long long> lds_devices{0};
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (dev >= 64 || !(lds_devices.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)k_gs_accumulate<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_gs_accumulate<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return ngp_fail(NGP_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+            lds_devices.fetch_or(bit, std::memory_order_release);
+        }
     }
     int cus = 256;
     {   // (hipGetDeviceProperties fills a 1.5 KB structure through the driver on every call: asked once per device)
         static std::atomic<int> cu_count[64];
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (dev < 64) {
             int c = cu_count[dev].load(std::memory_order_relaxed);
             if (c == 0) {
                 hipDeviceProp_t p;

@@ -426,14 +426,18 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restr
     }
 }
 
-// The slots [bases[2], M) that no ray of the call fills, zeroed like the torch.zeros buffers the reference's wrapper hands in (raymarching.py:205-208;
-// a zero delta marks a sample that does not exist, raymarching.cu:548).  Ray slots are prefix sums, so from the first ray that does not fit on nothing
-// is written: one contiguous tail.
+// The slots no ray of the call fills, zeroed like the torch.zeros buffers the reference's wrapper hands in (raymarching.py:205-208; a zero delta marks
+// a sample that does not exist, raymarching.cu:548): the tail [bases[2], M) -- ray slots are prefix sums, so from the first ray that does not fit on
+// nothing is written -- and the head [0, bases[0]) below the point base the caller's counter[0] held at entry (0 for every caller in this repository;
+// a caller that hands in a pre-advanced step_counter gets zeros there as from the reference).
 __global__ __launch_bounds__(RM_BLOCK) void k_march_train_zero_tail(const uint32_t* __restrict__ bases, uint32_t M, float* __restrict__ xyzs,
                                                                     float* __restrict__ dirs, float* __restrict__ deltas) {
     const uint32_t lo = bases[2] < M ? bases[2] : M;
     for (uint64_t i = 3ull * lo + blockIdx.x * RM_BLOCK + threadIdx.x; i < 3ull * M; i += (uint64_t)gridDim.x * RM_BLOCK) { xyzs[i] = 0.0f; dirs[i] = 0.0f; }
     for (uint64_t i = 2ull * lo + blockIdx.x * RM_BLOCK + threadIdx.x; i < 2ull * M; i += (uint64_t)gridDim.x * RM_BLOCK) deltas[i] = 0.0f;
+    const uint32_t head = bases[0] < M ? bases[0] : M;
+    for (uint64_t i = blockIdx.x * RM_BLOCK + threadIdx.x; i < 3ull * head; i += (uint64_t)gridDim.x * RM_BLOCK) { xyzs[i] = 0.0f; dirs[i] = 0.0f; }
+    for (uint64_t i = blockIdx.x * RM_BLOCK + threadIdx.x; i < 2ull * head; i += (uint64_t)gridDim.x * RM_BLOCK) deltas[i] = 0.0f;
 }
 
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_write(march_args a, int* __restrict__ rays,

@@ -92,41 +92,54 @@ def offsets_max_rows(offsets):
 
 import os as _os
 
-# table_gradient_binned(on_group=...): the table is summed in this many groups of levels, finest first (NGP_LEVEL_GROUPS overrides; 1 = one launch, the
-# whole table handed over at the end).  Every extra group costs a launch of the summing kernel with its own tail (measured on one MI355X, forced
-# single-rank RCCL, ms per steady / early step: 1 group 1.64 / 3.64, 2 groups 1.66 / 3.69, 4 groups 1.78 / 3.90) and hides that group's share of the
-# all-reduce: two groups (levels 8-15, then 0-7) cost 0.02 ms and leave 34 % of the table (8.6 MB of halves) exposed.
+# table_gradient_binned(on_group=...): the table is summed in this many groups of levels, finest first (1 = one launch, the whole table handed over at
+# the end).  Every extra group costs a launch of the summing kernel with its own tail (measured on one MI355X, forced single-rank RCCL, ms per steady /
+# early step: 1 group 1.64 / 3.64, 2 groups 1.66 / 3.69, 4 groups 1.78 / 3.90) and hides that group's share of the all-reduce: two groups (levels 8-15,
+# then 0-7) cost 0.02 ms and leave 34 % of the table (8.6 MB of halves) exposed.  This is only the DEFAULT of a caller that names no count: the
+# data-parallel trainer passes its own, rank-checked value (ngp/train.py GradExchange.level_groups) -- a collective schedule must not depend on a
+# per-process environment variable.
 LEVEL_GROUPS = int(_os.environ.get("NGP_LEVEL_GROUPS", "2"))
+PHASE_MAX_POINTS = 1 << 22             # ngp_grid_scatter_binned_phase takes one pass; larger batches go through the multi-pass entry point
 
 
-def table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, align_corners, out_dtype=torch.float32, out_scale=1.0, on_group=None):
+def level_group_rows(offsets, L, groups):
+    """[(row_lo, row_hi)] of the level groups in the order they are handed over (finest levels first).  A function of the level table and the group
+    count ONLY: every rank of a data-parallel job posts the same all-reduces whatever its own batch looked like."""
+    bounds = offsets_info(offsets)[2]
+    groups = max(1, min(int(groups), L))
+    cuts = [round(L * g / groups) for g in range(groups + 1)]
+    return [(cuts[g], cuts[g + 1], int(bounds[cuts[g]]), int(bounds[cuts[g + 1]])) for g in range(groups - 1, -1, -1)]
+
+
+def table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, align_corners, out_dtype=torch.float32, out_scale=1.0, on_group=None, groups=None):
     """grad [L,B,2] half (level-major), inputs [B,3] float32 in [0,1] -> the table gradient [sO,2] in `out_dtype`, summed on chip
     (ngp_grid_scatter_binned).  Shared by _grid_encode.backward and the field's native training step (ngp/field.py).
     on_group(out, row_lo, row_hi): called after the rows [row_lo, row_hi) of `out` (a group of levels, finest levels first, the few rows of the
-    coarsest levels last) have been queued -- the data-parallel gradient exchange starts their all-reduce while the next group is summed."""
+    coarsest levels last) have been queued -- the data-parallel gradient exchange starts their all-reduce while the next group is summed.
+    The SEQUENCE of on_group calls (row ranges, order) depends on (offsets, L, groups) only, never on B: B is a rank's own sample count, and ranks whose
+    batches fall on different sides of a size limit must still post matching collectives (an empty batch hands over zeros; a batch beyond the one-pass
+    limit is summed by the multi-pass entry point first and handed over in the same pieces)."""
     lib = _hip.lib()
     rows, n, bounds = offsets_info(offsets)
     out = torch.empty(n, 2, dtype=out_dtype, device=inputs.device)
     ws = _hip.workspace(lib.ngp_grid_scatter_binned_workspace(B, L), inputs.device)
-    if on_group is not None and 0 < B <= (1 << 22) and L >= 2:
-        groups = min(LEVEL_GROUPS, L)
-        cuts = [round(L * g / groups) for g in range(groups + 1)]
+    pieces = level_group_rows(offsets, L, LEVEL_GROUPS if groups is None else groups) if on_group is not None else None
+    if pieces is not None and len(pieces) > 1 and 0 < B <= PHASE_MAX_POINTS:
         args = (B, L)
         tail = (float(S), H, rows, gridtype, int(align_corners), _hip.dtype_code(out_dtype), float(out_scale), _hip.ptr(ws), ws.numel(), _hip.stream())
         with _hip.timed("grid_encode_backward"):
             _hip.check(lib.ngp_grid_scatter_binned_phase(1, _hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), *args, 0, L, *tail), "grid_scatter_binned_phase")
-            for g in range(groups - 1, -1, -1):
-                lo, hi = cuts[g], cuts[g + 1]
+            for lo, hi, row_lo, row_hi in pieces:
                 _hip.check(lib.ngp_grid_scatter_binned_phase(2, _hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), *args, lo, hi, *tail),
                            "grid_scatter_binned_phase")
-                on_group(out, int(bounds[lo]), int(bounds[hi]))
+                on_group(out, row_lo, row_hi)
         return out
     with _hip.timed("grid_encode_backward"):
         _hip.check(lib.ngp_grid_scatter_binned(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), B, L, float(S), H, rows, gridtype,
                                                int(align_corners), _hip.dtype_code(out_dtype), float(out_scale), _hip.ptr(ws), ws.numel(), _hip.stream()),
                    "grid_scatter_binned")
-    if on_group is not None:
-        on_group(out, 0, n)
+    for lo, hi, row_lo, row_hi in pieces or ():
+        on_group(out, row_lo, row_hi)
     return out
 
 

@@ -119,7 +119,8 @@ class _field_train(Function):
                 grad_emb = G.table_gradient_binned(grad_enc, inputs, enc.offsets, M, enc.num_levels, S, enc.base_resolution, enc.gridtype_id,
                                                    enc.align_corners, out_dtype=torch.float16 if sink is not None else torch.float32,
                                                    out_scale=(1.0 / sink.world_size()) if sink is not None else 1.0,
-                                                   on_group=(lambda out, r0, r1: sink.deliver_rows(enc.embeddings, out, r0, r1)) if sink is not None else None)
+                                                   on_group=(lambda out, r0, r1: sink.deliver_rows(enc.embeddings, out, r0, r1)) if sink is not None else None,
+                                                   groups=getattr(sink, "level_groups", None))
                 delivered_table = sink is not None       # group by group, finest levels first: their all-reduce runs while the coarser ones are summed
             else:
                 grad_emb = torch.zeros_like(emb_half)

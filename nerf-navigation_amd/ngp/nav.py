@@ -277,7 +277,7 @@ class _nav_run(torch.autograd.Function):
         # the per-sample record the backward consumes (108 B per sample); not kept when nobody will ask for a gradient
         need = any(ctx.needs_input_grad[:2])
         saved = _hip.workspace(L.ngp_nav_run_saved_bytes(N, int(num_steps)), rays_o.device) if need else None
-        with torch.cuda.device(rays_o.device):
+        with torch.cuda.device(rays_o.device), _hip.timed("nav_run_forward"):
             _hip.check(L.ngp_nav_run_forward(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
                                              N, int(num_steps), aabb, bgc, _hip.ptr(image), _hip.ptr(depth), _hip.ptr(ws),
                                              _hip.ptr(saved), saved.numel() if need else 0, _hip.stream()), "nav_run_forward")
@@ -294,7 +294,7 @@ class _nav_run(torch.autograd.Function):
         N = rays_o.shape[0]
         go, gd = torch.empty_like(rays_o), torch.empty_like(rays_d)
         st, prep = ctx.owner.struct()
-        with torch.cuda.device(rays_o.device):
+        with torch.cuda.device(rays_o.device), _hip.timed("nav_run_backward"):
             _hip.check(_hip.lib().ngp_nav_run_backward(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
                                                        N, ctx.num_steps, ctx.aabb, ctx.bg, _hip.ptr(g_image.contiguous().float()),
                                                        _hip.ptr(g_depth.contiguous().float()), _hip.ptr(g_ws.contiguous().float()),

@@ -36,7 +36,13 @@ class GradExchange:
     backward reduces what autograd left in `.grad` and completes the delivered ones.  `stats` counts the bytes and (with
     `timing=True`, CUDA only) the host-visible wait of the last step."""
 
-    def __init__(self, params, big_numel=1 << 20, timing=False):
+    def __init__(self, params, big_numel=1 << 20, timing=False, level_groups=None):
+        """level_groups: in how many pieces (groups of levels, finest first) the native scatter hands the table gradient over (gridencoder/grid.py
+        table_gradient_binned).  It shapes the sequence of all-reduces, so it must be the same on every rank: the first active step checks that
+        (`_check_rank_invariants`).  Default: NGP_LEVEL_GROUPS of the launching environment, else 2."""
+        import os
+        self.level_groups = int(os.environ.get("NGP_LEVEL_GROUPS", "2")) if level_groups is None else int(level_groups)
+        self._checked = False
         self.params = [p for p in params if p.requires_grad]
         self.big = [p for p in self.params if p.numel() >= big_numel]
         self.small = [p for p in self.params if p.numel() < big_numel]
@@ -147,6 +153,20 @@ class GradExchange:
 
     def begin_step(self):
         self.stats["allreduce_bytes"] = 0
+        if not self._checked and self.active():
+            self._check_rank_invariants()
+
+    def _check_rank_invariants(self):
+        """once, collectively: everything that decides WHICH all-reduces a step posts must agree across ranks -- the level-group count and the parameter
+        sizes.  A mismatch (say NGP_LEVEL_GROUPS set for one process only) would otherwise surface as a hang inside RCCL."""
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        mine = torch.tensor([self.level_groups, len(self.params), sum(p.numel() for p in self.params)], dtype=torch.int64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"GradExchange: ranks disagree on (level_groups, parameter count, parameter elements): min {lo.tolist()} max {hi.tolist()}")
+        self._checked = True
 
     def exposed_ms(self):
         """GPU time between the end of the backward and the last gradient being ready (events on the compute stream): what the step
@@ -306,7 +326,12 @@ class NGPTrainer:
         if fused_adam is None:
             fused_adam = self.device_type == "cuda"
         if native_adam is None:
-            native_adam = self.device_type == "cuda" and all(p.dtype == torch.float32 and p.is_contiguous() for p in renderer.field.parameters())
+            # the native launch takes up to ADAM_MAX_TENSORS float32 tensors (csrc/adam.hip); a field with more of them (deeper nn.Linear stacks, a
+            # background network) keeps torch's Adam + GradScaler, as before the native optimiser existed
+            import ngp_hip as _hip
+            field_params = list(renderer.field.parameters())
+            native_adam = (self.device_type == "cuda" and len(field_params) <= _hip.ADAM_MAX_TENSORS
+                           and all(p.dtype == torch.float32 and p.is_contiguous() for p in field_params))
         self.native_adam = bool(native_adam)
         if self.native_adam:
             # ... and the native one (default): the non-finite check, GradScaler's decisions and recurrence, Adam and the float16 copy of the
@@ -325,11 +350,16 @@ class NGPTrainer:
         renderer.grid_seed = int(seed)
 
     # ---- the direct step: the autograd graph's function bodies, called in order ---------------------------------------------------------------
-    def _direct_applies(self, ren, field, rays_o, target, bg_color, march):
+    def _direct_applies(self, ren, field, rays_o, rays_d, target, bg_color, march):
+        """The direct step calls the undecorated bodies, so nothing casts or checks the operands for it (custom_fwd(cast_inputs=float32) and the autograd
+        route's `image.shape == target.shape` do that elsewhere): every operand must already be what the kernels read -- float32, on the GPU, rays_d shaped
+        like rays_o, one target colour per ray.  Anything else takes the autograd route, which casts or raises."""
         from .field import NGPFieldFF
         p = getattr(getattr(field, "encoder", None), "embeddings", None)
         return (self.direct and self.native_adam and self.fp16 and isinstance(field, NGPFieldFF) and field.fused_training and ren.cuda_ray
                 and getattr(ren, "bg_radius", -1) <= 0 and rays_o.is_cuda and rays_o.dtype == torch.float32 and target.dtype == torch.float32
+                and rays_d.is_cuda and rays_d.dtype == torch.float32 and rays_d.shape == rays_o.shape and rays_o.shape[-1] == 3
+                and target.is_cuda and target.numel() == rays_o.numel() and target.shape[-1] == 3
                 and isinstance(bg_color, (int, float)) and p is not None and p.requires_grad and p.dtype == torch.float32
                 and field.sigma_net.weights.requires_grad and field.color_net.weights.requires_grad and field._fused_shape_ok()
                 and set(march) <= {"dt_gamma", "max_steps"} and rays_o.numel() > 0)
@@ -408,7 +438,7 @@ class NGPTrainer:
         if hasattr(field, "grad_sink"):
             field.grad_sink = self.exchange if self.exchange.active() else None     # the native backward hands its gradients over as they appear
         try:
-            if self._direct_applies(ren, field, rays_o, target, bg_color, march):
+            if self._direct_applies(ren, field, rays_o, rays_d, target, bg_color, march):
                 loss = self._direct_forward_backward(ren, field, rays_o, rays_d, target, bg_color, **march)
             else:
                 with torch.autocast(self.device_type, dtype=torch.float16, enabled=self.fp16):

@@ -10,6 +10,9 @@ freq_encoder.npz : inputs and outputs of the REFERENCE's pure-torch encoding.Fre
                 CPU float32, and the input gradients torch autograd gives for a fixed output gradient.
 The reference holds no other runnable code for the hot path (its kernels are CUDA) and no fixtures of its own.
 """
+import sys
+
+sys.dont_write_bytecode = True      # nothing is written under /root/reference (no __pycache__ beside the files this script reads or imports)
 import importlib.util
 import os
 import warnings

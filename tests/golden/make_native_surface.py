@@ -3,6 +3,9 @@
 module the exported function names (`m.def("name", ...)` in <pkg>/src/bindings.cpp) and, from the declaration in <pkg>/src/<pkg>.h,
 the kind of each argument in order ("tensor" for at::Tensor, else the C type).  Read as text in the authoring container only;
 tests/test_native_modules.py compares the shims built from nerf-navigation_amd/bindings/ against it."""
+import sys
+
+sys.dont_write_bytecode = True      # nothing is written under /root/reference (no __pycache__ beside the files this script reads or imports)
 import json
 import os
 import re

@@ -9,6 +9,9 @@ and pow(e, n) with a literal integer n; nothing else is accepted and nothing is 
 inputs, outputs [B,64] and dy_dx [B,3,64].  Run in the authoring container only: /root/reference does not exist on the GPU box.
 The .npz is data (inputs and expected values); no reference source text is stored in it or anywhere else in the repository.
 """
+import sys
+
+sys.dont_write_bytecode = True      # nothing is written under /root/reference (no __pycache__ beside the files this script reads or imports)
 import os
 import re
 

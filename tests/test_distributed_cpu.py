@@ -181,7 +181,7 @@ def test_two_rank_trainer_replicas_stay_identical():
     procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=90) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -258,3 +258,118 @@ def test_two_rank_delivered_half_table_gradient_equals_the_float32_exchange_to_h
         assert np.allclose(np.concatenate([f(r[4]), f(r[5])]), mean_w, rtol=1e-6, atol=1e-7)
         assert np.array_equal(f(r[6]), np.full(10, 1.5, np.float32))
         assert r[8] == 6000 * 2 * 2 + (7168 + 11264) * 4 + 10 * 4                       # half table + float32 bucket + the small float32 bucket
+
+
+class _FakeScatterLib:
+    """libngp_hip's binned-scatter entry points as host functions that fill the output rows they would have written with a value that depends on
+    the rank's batch size: enough to run gridencoder.grid.table_gradient_binned's CONTROL FLOW (which collectives, in which order) without a GPU"""
+
+    def __init__(self, offsets):
+        self.bounds = [int(v) for v in offsets]
+
+    def ngp_grid_scatter_binned_workspace(self, B, L):
+        return 64
+
+    def _value(self, B):
+        return 0.0 if B == 0 else float(B % 1000) / 8.0
+
+    def ngp_grid_scatter_binned_phase(self, phase, grad, inputs, offsets, out, B, L, lo, hi, *rest):
+        if phase == 2:
+            out.tensor[self.bounds[lo]:self.bounds[hi]] = self._value(B) * rest[6]         # out_scale
+        return 0
+
+    def ngp_grid_scatter_binned(self, grad, inputs, offsets, out, B, L, *rest):
+        out.tensor[:] = self._value(B) * rest[6]
+        return 0
+
+
+def _straddle_worker(rank, world, port, out, sizes, groups):
+    sys.path.insert(0, ROOT)
+    import importlib
+    importlib.import_module("nerf-navigation_amd")
+    import ngp_hip
+    from gridencoder import grid as G
+    from ngp import workload as W
+    from ngp.train import GradExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        offsets = torch.from_numpy(W.grid_offsets()[0])
+        ngp_hip.lib = lambda: _FakeScatterLib(offsets)
+        table = torch.nn.Parameter(torch.zeros(int(offsets[-1]), 2))
+        ex = GradExchange([table], level_groups=groups)
+        B = sizes[rank]
+        dummy = torch.empty(1)
+        posted = []
+
+        def on_group(full, lo, hi):
+            posted.append((lo, hi))
+            ex.deliver_rows(table, full, lo, hi)
+        ex.begin_step()                                                     # (the rank-invariance check runs here)
+        G.table_gradient_binned(dummy, dummy, offsets, B, 16, 8 / 15, 16, 0, False, out_dtype=torch.float16, out_scale=1.0 / world, on_group=on_group,
+                                groups=ex.level_groups)
+        ex()
+        out.put((rank, posted, float(table.grad.min()), float(table.grad.max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_straddle(sizes, groups=2):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_straddle_worker, args=(r, world, port, q, sizes, groups)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=90) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_collective_schedule_does_not_depend_on_the_ranks_batch_sizes():
+    """B is a rank's OWN sample count.  One rank above the one-pass limit of the grouped scatter (2^22 points) and one below, or one
+    rank with an empty batch, must still post the same all-reduces (same row ranges, same order) -- a mismatch hangs RCCL or mixes up gradients."""
+    for sizes in ((100, (1 << 22) + 1), (0, 100), ((1 << 22) + 1, 0)):
+        res = _run_straddle(sizes)
+        assert res[0][1] == res[1][1] and len(res[0][1]) == 2 and res[0][1][0][1] == 6328848 and res[0][1][-1][0] == 0
+        want = sum((0.0 if B == 0 else (B % 1000) / 8.0) / 2 for B in sizes)
+        for r in res:
+            assert r[2] == r[3] == want, (sizes, r)                            # the mean of the two ranks' "gradients" on every row, on both ranks
+    res = _run_straddle((5, 7), groups=4)
+    assert res[0][1] == res[1][1] and len(res[0][1]) == 4
+
+
+def _mismatch_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import importlib
+    importlib.import_module("nerf-navigation_amd")
+    from ngp.train import GradExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = GradExchange([torch.nn.Parameter(torch.zeros(8))], level_groups=2 + rank)
+        try:
+            ex.begin_step()
+            out.put((rank, "no error"))
+        except RuntimeError as e:
+            out.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_level_group_mismatch_is_an_error_not_a_hang():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("ranks disagree" in msg for _, msg in res), res

@@ -189,7 +189,17 @@ def test_direct_step_equals_the_autograd_step(dev):
     order-independent sums) is the same bits, the weight gradients agree to their float32 atomics, and the runs stay together"""
     a, tra, la, _ = _trained(dev, True, steps=1, direct=True)
     b, trb, lb, _ = _trained(dev, True, steps=1, direct=False)
-    assert tra._direct_applies(a, a.field, torch.zeros(1, 4, 3, device=dev), torch.zeros(1, 4, 3, device=dev), 1, {"max_steps": 256})
+    z = torch.zeros(1, 4, 3, device=dev)
+    assert tra._direct_applies(a, a.field, z, z, z, 1, {"max_steps": 256})
+    # ADVICE r3: the direct step calls undecorated bodies -- nothing casts or checks its operands, so anything but float32 GPU rays of one shape and one
+    # target colour per ray must take the autograd route (which casts rays_d like custom_fwd(cast_inputs=float32) did, or raises on the target)
+    assert not tra._direct_applies(a, a.field, z, z.double(), z, 1, {})
+    assert not tra._direct_applies(a, a.field, z, z.half(), z, 1, {})
+    assert not tra._direct_applies(a, a.field, z, z[:, :3], z, 1, {})
+    assert not tra._direct_applies(a, a.field, z, z.cpu(), z, 1, {})
+    assert not tra._direct_applies(a, a.field, z, z, z.cpu(), 1, {})
+    assert not tra._direct_applies(a, a.field, z, z, torch.zeros(1, 4, 4, device=dev), 1, {})
+    assert not tra._direct_applies(a, a.field, z, z, torch.zeros(1, 3, 3, device=dev), 1, {})
     assert la == lb                                                                    # the loss's summation tree is fixed
     fa, fb = a.field, b.field
     assert torch.equal(fa.encoder.embeddings.grad, fb.encoder.embeddings.grad) and fa.encoder.embeddings.grad.abs().max() > 0
@@ -223,7 +233,7 @@ def test_trainer_configurations_outside_the_direct_step_learn_with_the_native_op
     field = (NGPField if field_kind == "linear" else NGPFieldFF)(bound=W.BOUND).to(dev)
     student = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
     tr = NGPTrainer(student, lr=1e-2, iters=600, fp16=fp16)
-    assert tr.native_adam and not tr._direct_applies(student, field, to, tc, 1, {"max_steps": 256})
+    assert tr.native_adam and not tr._direct_applies(student, field, to, td, tc, 1, {"max_steps": 256})
     gen = torch.Generator(device=dev).manual_seed(1)
     losses = []
     for k in range(60):
@@ -260,3 +270,44 @@ def test_native_adam_at_the_field_s_full_size(dev):
             _close(a, b, f"param {i}", k)
     assert torch.equal(mine[0].detach()[~touched], start[~touched])
     assert torch.equal(half, mine[0].detach().to(torch.float16)) and opt.step_count() == 3
+
+
+def test_a_step_with_float64_directions_or_a_short_target_does_not_reach_the_direct_kernels(dev):
+    """float64 rays_d trains like float32 rays_d (cast by the autograd route's custom_fwd, as in the reference's wrappers); a target with fewer colours than
+    rays raises instead of being read past its end"""
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    from ngp.render import NGPRenderer
+    from ngp.train import NGPTrainer
+    o, d = W.get_rays(W.orbit_pose(2, 8), W.intrinsics(24, 24), 24, 24)
+    to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+    tc = torch.rand(1, 576, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    losses = []
+    for dirs in (td, td.double()):
+        torch.manual_seed(0)
+        ren = NGPRenderer(NGPFieldFF(bound=W.BOUND).to(dev), bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
+        tr = NGPTrainer(ren, lr=1e-2, iters=100, fp16=True)
+        losses.append([float(tr.step(to, dirs, tc, bg_color=1, max_steps=128)) for _ in range(3)])
+    assert np.allclose(losses[0], losses[1], rtol=2e-3), losses
+    with pytest.raises((RuntimeError, AssertionError, ValueError)):
+        tr.step(to, td, tc[:, :500], bg_color=1, max_steps=128)
+        torch.cuda.synchronize()
+
+
+def test_a_field_with_more_tensors_than_the_native_launch_takes_keeps_torch_adam(dev):
+    """NativeAdam takes ADAM_MAX_TENSORS (16) tensors per launch; a deeper nn.Linear field must construct and train as it did with torch.optim.Adam"""
+    import ngp_hip
+    from ngp import workload as W
+    from ngp.field import NGPField
+    from ngp.render import NGPRenderer
+    from ngp.train import NGPTrainer
+    torch.manual_seed(0)
+    field = NGPField(bound=W.BOUND, num_layers=9, num_layers_color=9).to(dev)
+    assert len(list(field.parameters())) > ngp_hip.ADAM_MAX_TENSORS
+    ren = NGPRenderer(field, bound=W.BOUND, cuda_ray=True, density_thresh=10.0).to(dev)
+    tr = NGPTrainer(ren, lr=1e-3, iters=100, fp16=False)
+    assert not tr.native_adam and isinstance(tr.opt, torch.optim.Adam)
+    o, d = W.get_rays(W.orbit_pose(2, 8), W.intrinsics(16, 16), 16, 16)
+    to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+    loss = tr.step(to, td, torch.rand(1, 256, 3, device=dev), bg_color=1, max_steps=64)
+    assert torch.isfinite(loss)

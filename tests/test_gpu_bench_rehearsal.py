@@ -44,3 +44,33 @@ def test_two_rank_training_line():
     j = _run(["--mode", "train", "--steps", "3", "--warmup", "1", "--settle", "2"])
     assert j["n_gpus"] == 2 and j["unit"] == "rays/s" and j["config"]["rays_per_step_per_gpu"] == 4096
     assert j["value"] > 0 and j["config"]["final_loss"] == j["config"]["final_loss"]      # finite loss after the exchanged steps
+
+
+def _run_bare(extra):
+    """the bare form the driver records (`python3 bench.py --gpus N ...`, no launcher, WORLD_SIZE unset): bench.py starts its own ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["NGP_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"] + extra, env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]      # stdout is the one JSON line and nothing else
+    return json.loads(lines[0])
+
+
+def test_bare_command_starts_its_own_ranks_render():
+    j = _run_bare(["--steps", "3", "--warmup", "1", "--res", "200"])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+
+
+def test_bare_command_starts_its_own_ranks_train():
+    j = _run_bare(["--mode", "train", "--steps", "3", "--warmup", "1", "--settle", "2"])
+    assert j["n_gpus"] == 2 and j["unit"] == "rays/s" and j["value"] > 0
+
+
+def test_bare_command_propagates_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["NGP_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu", "--scaling", "strong", "--path", "drop_in", "--steps", "1",
+                          "--warmup", "0", "--res", "64"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]      # (strong scaling asserts path == fused)

@@ -197,6 +197,27 @@ def test_march_rays_train_bit_exact(oracle, dev, scene, perturb, mode):
         assert (r_r[:, 1] + r_r[:, 2] >= x_r.shape[0]).any(), "test must include dropped rays"
 
 
+def test_march_rays_train_with_a_pre_advanced_counter(oracle, dev, scene):
+    """the public wrapper hands UNINITIALISED buffers to ngp_march_rays_train_filled.  With a caller-supplied step_counter that is not zero
+    (point base 777, ray base 0) the slots [0, 777) that no ray fills must read as zeros, like the reference's torch.zeros buffers -- a zero delta is
+    what marks a slot as empty (raymarching.cu:548).  The oracle marches into zero-filled buffers."""
+    import raymarching
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    c_ref = np.array([777, 0], np.int32)
+    x_r, d_r, l_r, r_r = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, c_ref, mean_count=40000, perturb=False, align=128,
+                                                 force_all_rays=False, dt_gamma=0.0, max_steps=1024)
+    junk = torch.full((1 << 22,), float("nan"), device=dev)          # poison the allocator's free blocks the wrapper's torch.empty will reuse
+    del junk
+    cnt = torch.tensor([777, 0], dtype=torch.int32, device=dev)
+    x, dd, l, r = raymarching.march_rays_train(t(o, dev), t(d, dev), BOUND, t(bf, dev), CAS, H, t(nears, dev), t(fars, dev), cnt, 40000, False, 128, False, 0.0, 1024)
+    assert_same_bits(cnt, c_ref, "counter")
+    assert_same_bits(r, r_r, "rays")
+    assert_same_bits(l, l_r, "deltas")
+    assert_same_bits(x, x_r, "xyzs")
+    assert_same_bits(dd, d_r, "dirs")
+    assert int(r_r[:, 1].min()) == 777 and not l_r[:777].any()
+
+
 @pytest.mark.parametrize("max_steps", [1024, 24])
 @pytest.mark.parametrize("perturb", [False, True])
 def test_wave_per_ray_count_pass_equals_lane_per_ray(oracle, dev, perturb, max_steps):
