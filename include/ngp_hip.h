@@ -369,14 +369,18 @@ int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const fl
 
 /* The field's training step in two calls: NeRFNetwork.forward (nerf/network_ff.py:51-77) under autocast and the backward autograd
  * runs through it (ffmlp/src/ffmlp.cu:410-518,749-895; activation.py:17-21; torch.sigmoid), for the default field shapes.
- * forward: as ngp_field_forward, and keeps the encoded features of every sample (64 B each) in `saved`
- *   (ngp_field_train_saved_bytes(M) bytes) -- the only activation kept; both networks are recomputed in the backward.
+ * forward: as ngp_field_forward, and keeps the encoded features of every sample (64 B each, level-major [16][M rounded up to 32] half2) in
+ *   `saved` (ngp_field_train_saved_bytes(M) bytes) -- the only activation kept; both networks are recomputed in the backward.
  * backward: grad_sigmas [M], grad_rgbs [M,3] f32 (gradients of the forward's outputs) ->
  *   grad_enc [16][M][2] f16, level-major: d(loss)/d(encoded features), the `grad` argument of ngp_grid_encode_backward;
  *   grad_sigma_weights [7168], grad_color_weights [11264] f32 in FFMLP's weight layout, rounded to half like the reference's grad_weights.
- *   field_host must describe the same half copies the forward used.  workspace: ngp_field_train_workspace(M) bytes whose first
- *   ngp_field_train_workspace(0) bytes are ZERO on entry (they are zero again on return). */
+ *   field_host must describe the same half copies the forward used.  workspace: ngp_field_train_workspace(M) bytes, contents arbitrary
+ *   (per-workgroup partial sums of the weight gradients, added in a fixed order: the gradients are bitwise reproducible; nothing to clear,
+ *   ngp_field_train_workspace(0) == 0). */
 size_t ngp_field_train_saved_bytes(uint32_t M);
+/* forward in two passes (default: the encoder level by level, one level's table live in L2 at a time, then the networks) or in one launch;
+ * same values and the same `saved` layout either way; returns the previous setting (process-wide: A/B timing, tests). */
+int ngp_field_train_set_two_pass(int enabled);
 size_t ngp_field_train_workspace(uint32_t M);
 int ngp_field_train_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
                             float* sigmas, float* rgbs, void* saved, size_t saved_bytes, void* stream);

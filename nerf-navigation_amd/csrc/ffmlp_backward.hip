@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void k_ffmlp_bwd_act(const _Float16* __restric
 // weight gradients
 // ---------------------------------------------------------------------------
 
-struct wgrad_job { const _Float16* G; const _Float16* A; float* out; int go, ai; };   // dW[go][ai] += G[B][go]^T . A[B][ai]
-struct wgrad_jobs { wgrad_job j[5]; int n; };
+struct wgrad_job { const _Float16* G; const _Float16* A; float* out; int go, ai; };   // dW[go][ai] = G[B][go]^T . A[B][ai], as one partial sum per workgroup column
+struct wgrad_jobs { wgrad_job j[5]; int n; uint32_t row_stride; };                    // row_stride: floats between the partial-sum rows of consecutive blockIdx.x
 
 static constexpr int WG_S = 32;                 // samples per step
 static constexpr int WG_LD = WG_S + 8;          // LDS row stride in halves (80 B: 16-byte aligned rows, staggered banks)
@@ -189,15 +189,10 @@ __global__ __launch_bounds__(256) void k_ffmlp_bwd_wgrad(wgrad_jobs jobs, uint32
         if (tid < nt * nu) {
             const int t = tid / nu, u = tid - t * nu;
             #pragma unroll
-            for (int rr = 0; rr < 4; rr++)                              // D: row o = 16t + 4g + rr, col i = 16u + r
-                unsafeAtomicAdd(job.out + (16 * t + 4 * g + rr) * job.ai + 16 * u + r, acc[q][rr]);
+            for (int rr = 0; rr < 4; rr++)                              // D: row o = 16t + 4g + rr, col i = 16u + r; plain stores into this column's row
+                job.out[(uint64_t)blockIdx.x * jobs.row_stride + (16 * t + 4 * g + rr) * job.ai + 16 * u + r] = acc[q][rr];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_ffmlp_bwd_cast(const float* __restrict__ ws, _Float16* __restrict__ gw, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) gw[i] = (_Float16)ws[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -240,9 +235,9 @@ extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const vo
     NGP_REQUIRE(activation == 0 && output_activation == 6, "ffmlp_backward: only ReLU hidden / no output activation");
     NGP_REQUIRE(B % 32 == 0, "ffmlp_backward: batch must be a multiple of 32 (the wrapper pads to 128)");
     const uint32_t nw = ffmlp_nparams(input_dim, output_dim, hidden_dim, num_layers);
-    NGP_REQUIRE(grad_weights && workspace && workspace_bytes >= sizeof(float) * (size_t)nw, "ffmlp_backward: grad_weights / workspace missing or too small");
+    NGP_REQUIRE(grad_weights && workspace && workspace_bytes >= ffmlp_partial_bytes(nw), "ffmlp_backward: grad_weights / workspace missing or too small");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)nw, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "ffmlp_backward: memset failed");
+    uint32_t gx = 0;                                                    // rows of partial sums written (0: an empty batch, all-zero gradients)
     if (B > 0) {
         NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer, "ffmlp_backward: null pointer");
         NGP_REQUIRE(!calc_grad_inputs || grad_inputs, "ffmlp_backward: calc_grad_inputs needs grad_inputs");
@@ -268,12 +263,16 @@ extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const vo
             jobs.j[jobs.n++] = wgrad_job{bb + (uint64_t)k * BW, fb + (uint64_t)mi * BW, ws + off_hid + mi * 64 * 64, 64, 64};
         }
         jobs.j[jobs.n++] = wgrad_job{bb + (uint64_t)(num_layers - 1) * BW, (const _Float16*)inputs, ws, 64, (int)input_dim};
-        uint32_t gx = ngp_div_up(B / WG_S, 4);
-        if (gx > 256) gx = 256;
+        gx = ngp_div_up(B / WG_S, 4);
+        const uint32_t rows = ffmlp_partial_rows(nw);
+        if (gx > rows) gx = rows;
         if (gx == 0) gx = 1;
+        jobs.row_stride = nw;
+        // no atomics: each workgroup column stores its partial sums as a row, added in a fixed order below (the reference's split-K CUTLASS GEMMs
+        // accumulate in half in an order its streams decide, ffmlp.cu:804-875; float atomics here made two identical runs differ in the last bits)
         hipLaunchKernelGGL(k_ffmlp_bwd_wgrad, dim3(gx, jobs.n), dim3(256), 0, s, jobs, B);
     }
-    hipLaunchKernelGGL(k_ffmlp_bwd_cast, dim3(ngp_div_up(nw, 256)), dim3(256), 0, s, (const float*)workspace, (_Float16*)grad_weights, nw);
+    ffmlp_sum_partials((const float*)workspace, gx, nw, grad_weights, s);
     NGP_CHECK_LAUNCH("ffmlp_backward");
     return NGP_OK;
 }

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void k_fg_transpose(const _Float16* __restrict
 
 // dW[go][ai] (f32, row stride ai) += G[B][go]^T A[B][ai]; blockIdx.y = 64 x 64 block of dW, blockIdx.x strides over 32-sample steps
 static constexpr int FGW_S = 32, FGW_LD = FGW_S + 8;
-__global__ __launch_bounds__(256) void k_fg_wgrad(const _Float16* __restrict__ G, int go, const _Float16* __restrict__ A, int ai, float* __restrict__ out, uint32_t B) {
+__global__ __launch_bounds__(256) void k_fg_wgrad(const _Float16* __restrict__ G, int go, const _Float16* __restrict__ A, int ai, float* __restrict__ out, uint32_t B,
+                                                  uint32_t row_stride /* floats between the partial-sum rows of consecutive blockIdx.x */) {
     __shared__ __attribute__((aligned(16))) _Float16 Gt[64 * FGW_LD];
     __shared__ __attribute__((aligned(16))) _Float16 At[64 * FGW_LD];
     const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, wave = threadIdx.x >> 6;
@@ -134,15 +135,41 @@ __global__ __launch_bounds__(256) void k_fg_wgrad(const _Float16* __restrict__ G
         if (tid < nt * nu) {
             const int t = tid / nu, u = tid - t * nu;
             #pragma unroll
-            for (int rr = 0; rr < 4; rr++)
-                unsafeAtomicAdd(out + (uint64_t)(o0 + 16 * t + 4 * g + rr) * ai + i0 + 16 * u + r, acc[q][rr]);
+            for (int rr = 0; rr < 4; rr++)                              // this workgroup column's row of the partial sums: plain stores, every element
+                out[(uint64_t)blockIdx.x * row_stride + (uint64_t)(o0 + 16 * t + 4 * g + rr) * ai + i0 + 16 * u + r] = acc[q][rr];
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_fg_cast(const float* __restrict__ ws, _Float16* __restrict__ gw, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) gw[i] = (_Float16)ws[i];
+// [rows][n] f32 partial sums -> half gradients: 16 chunks of consecutive rows, each summed front to back by one thread, then the chunk sums front to
+// back -- a fixed order, whatever order the workgroups that wrote the rows finished in
+static constexpr uint32_t FG_SUM_COLS = 64, FG_SUM_CHUNKS = 16;
+__global__ __launch_bounds__(FG_SUM_COLS * FG_SUM_CHUNKS) void k_fg_sum_partials(const float* __restrict__ ws, uint32_t rows, uint32_t n, _Float16* __restrict__ gw) {
+    __shared__ float part[FG_SUM_CHUNKS][FG_SUM_COLS];
+    const uint32_t col = threadIdx.x % FG_SUM_COLS, chunk = threadIdx.x / FG_SUM_COLS;
+    const uint32_t i = blockIdx.x * FG_SUM_COLS + col;
+    const uint32_t per = (rows + FG_SUM_CHUNKS - 1) / FG_SUM_CHUNKS;
+    const uint32_t r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float sum = 0.0f;
+    if (i < n)
+        for (uint32_t r = r0; r < r1; r++) sum += ws[(size_t)r * n + i];
+    part[chunk][col] = sum;
+    __syncthreads();
+    if (chunk == 0 && i < n) {
+        float v = part[0][col];
+        #pragma unroll
+        for (uint32_t c = 1; c < FG_SUM_CHUNKS; c++) v += part[c][col];
+        gw[i] = (_Float16)v;
+    }
+}
+
+uint32_t ffmlp_partial_rows(uint32_t nw) {
+    const uint64_t fit = (64ull << 20) / (4ull * (nw ? nw : 1u));
+    return (uint32_t)(fit > 256 ? 256 : (fit ? fit : 1));
+}
+size_t ffmlp_partial_bytes(uint32_t nw) { return ((size_t)ffmlp_partial_rows(nw) * nw * sizeof(float) + 255) & ~(size_t)255; }
+void ffmlp_sum_partials(const float* partials, uint32_t rows, uint32_t nw, void* grad_weights_half, hipStream_t s) {
+    hipLaunchKernelGGL(k_fg_sum_partials, dim3(ngp_div_up(nw, FG_SUM_COLS)), dim3(FG_SUM_COLS * FG_SUM_CHUNKS), 0, s, partials, rows, nw, (_Float16*)grad_weights_half);
 }
 
 // ---------------------------------------------------------------------------
@@ -190,8 +217,8 @@ int ffmlp_generic_forward(const void* inputs, const void* weights, uint32_t B, u
 static uint32_t fg_nparams(uint32_t in, uint32_t out, uint32_t hid, uint32_t nl) { return hid * (in + hid * (nl - 1) + out); }
 
 size_t ffmlp_generic_backward_workspace(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers) {
-    const size_t nw = fg_nparams(input_dim, output_dim, hidden_dim, num_layers);
-    return sizeof(float) * nw + sizeof(_Float16) * nw + 256;
+    const uint32_t nw = fg_nparams(input_dim, output_dim, hidden_dim, num_layers);
+    return ffmlp_partial_bytes(nw) + sizeof(_Float16) * (size_t)nw + 256;       // [partial sums of the weight gradients | transposed weights]
 }
 
 int ffmlp_generic_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B, uint32_t input_dim,
@@ -202,8 +229,8 @@ int ffmlp_generic_backward(const void* grad, const void* inputs, const void* wei
     NGP_REQUIRE(grad_weights && workspace && workspace_bytes >= ffmlp_generic_backward_workspace(input_dim, output_dim, hidden_dim, num_layers),
                 "ffmlp_backward: grad_weights / workspace missing or too small");
     float* ws = (float*)workspace;
-    _Float16* wt = (_Float16*)((unsigned char*)workspace + (((size_t)nw * sizeof(float) + 255) & ~(size_t)255));
-    if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)nw, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "ffmlp_backward: memset failed");
+    _Float16* wt = (_Float16*)((unsigned char*)workspace + ffmlp_partial_bytes(nw));
+    uint32_t gx = 0;                                                        // rows of partial sums written (0: an empty batch, all-zero gradients)
     if (B > 0) {
         NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer, "ffmlp_backward: null pointer");
         NGP_REQUIRE(!calc_grad_inputs || grad_inputs, "ffmlp_backward: calc_grad_inputs needs grad_inputs");
@@ -228,16 +255,17 @@ int ffmlp_generic_backward(const void* grad, const void* inputs, const void* wei
         if (calc_grad_inputs)
             hipLaunchKernelGGL(k_fg_layer<2>, dim3(fg_blocks(B)), dim3(256), 0, s, bb + (num_layers - 1) * BW, wt, (_Float16*)grad_inputs, (const _Float16*)nullptr, B, H, (int)input_dim, (uint32_t)FG_NONE);
         // weight gradients (ffmlp.cu:804-810, 851-857, 869-875)
-        uint32_t gx = ngp_div_up(ngp_div_up(B, FGW_S), 4);
-        gx = gx > 256 ? 256 : (gx ? gx : 1);
+        gx = ngp_div_up(ngp_div_up(B, FGW_S), 4);
+        const uint32_t rows = ffmlp_partial_rows(nw);
+        gx = gx > rows ? rows : (gx ? gx : 1);
         const int nbh = (H + 63) / 64, nbin = ((int)input_dim + 63) / 64;
-        hipLaunchKernelGGL(k_fg_wgrad, dim3(gx, 1 * nbh), dim3(256), 0, s, (const _Float16*)grad, (int)output_dim, fb + (num_layers - 1) * BW, H, ws + off_last, B);
+        hipLaunchKernelGGL(k_fg_wgrad, dim3(gx, 1 * nbh), dim3(256), 0, s, (const _Float16*)grad, (int)output_dim, fb + (num_layers - 1) * BW, H, ws + off_last, B, nw);
         for (uint32_t k = 0; k + 1 < num_layers; k++) {
             const uint32_t mi = num_layers - 2 - k;
-            hipLaunchKernelGGL(k_fg_wgrad, dim3(gx, nbh * nbh), dim3(256), 0, s, bb + k * BW, H, fb + mi * BW, H, ws + off_hid + mi * H * H, B);
+            hipLaunchKernelGGL(k_fg_wgrad, dim3(gx, nbh * nbh), dim3(256), 0, s, bb + k * BW, H, fb + mi * BW, H, ws + off_hid + mi * H * H, B, nw);
         }
-        hipLaunchKernelGGL(k_fg_wgrad, dim3(gx, nbh * nbin), dim3(256), 0, s, bb + (num_layers - 1) * BW, H, (const _Float16*)inputs, (int)input_dim, ws, B);
+        hipLaunchKernelGGL(k_fg_wgrad, dim3(gx, nbh * nbin), dim3(256), 0, s, bb + (num_layers - 1) * BW, H, (const _Float16*)inputs, (int)input_dim, ws, B, nw);
     }
-    hipLaunchKernelGGL(k_fg_cast, dim3(ngp_div_up(nw, 256)), dim3(256), 0, s, (const float*)ws, (_Float16*)grad_weights, nw);
+    ffmlp_sum_partials(ws, gx, nw, grad_weights, s);
     return NGP_OK;
 }

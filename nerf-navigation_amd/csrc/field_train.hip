@@ -22,8 +22,8 @@
 // core returns the same values transposed -- D[sample 4g+r][feature lane&15] -- exactly (one product per sum, f32).  Two 16-sample tiles
 // give the 8 values per lane of a K = 32 operand; the sample order inside K is the same for both operands, so it does not matter.
 // Every wave accumulates all 72 16x16 tiles of the seven weight gradients in registers (f32) over all its samples; at the end the four
-// waves of a workgroup are summed through LDS and added to a global f32 workspace, which k_field_train_wgrad_finish rounds to the
-// reference's half precision and clears.
+// waves of a workgroup are summed through LDS and stored as that workgroup's row of a partial-sum buffer; k_field_train_wgrad_finish adds
+// the rows in a fixed order and rounds to the reference's half precision: no atomics, the same bits on every run.
 // ===========================================================================
 static constexpr int FT_NBWD = 38;                     // W^T fragments of the seven backward steps
 static constexpr int FT_NSEL = 7;                      // selection fragments
@@ -124,14 +124,97 @@ __device__ __forceinline__ ngp_h8 ft_transposed(ngp_h8 x0, ngp_h8 x1, ngp_h8 sel
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The kept features: LEVEL-MAJOR, enc[level][Mp] half2 (Mp = M rounded up to 32), 64 B per sample.  Lane (g, s) of a 16-sample tile owns levels
+// 4i + g (slots 2i, 2i + 1 of its B fragment): four 4-byte accesses, each a 64-byte segment per lane group -- fully used lines either way round.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ ngp_h8 ft_enc_load(const uint32_t* __restrict__ enc, uint32_t Mp, uint32_t m, int g) {
+    uint32_t v[4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = enc[(size_t)(4 * i + g) * Mp + m];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 q = {v[0], v[1], v[2], v[3]};
+    return __builtin_bit_cast(ngp_h8, q);
+}
+__device__ __forceinline__ void ft_enc_store(uint32_t* __restrict__ enc, uint32_t Mp, uint32_t m, int g, const ngp_h8 x) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 q = __builtin_bit_cast(u4, x);
+    #pragma unroll
+    for (int i = 0; i < 4; i++) enc[(size_t)(4 * i + g) * Mp + m] = q[i];
+}
+
+// Pass 1 of the two-pass forward: the hash-grid encoding LEVEL BY LEVEL (blockIdx.y = level, dispatched level-major: the whole chip works on one
+// level's table -- 2 MB for a hashed level -- at a time, which an XCD's 4 MB L2 holds; the one-pass kernel has all 16 levels' 25 MB live at once and
+// ran at an L2 hit rate of 0.46 on ray-ordered points, 950 B per point past L2: profiles/r15_gather_rate.md).  One lane per sample.
+// Arithmetic per (sample, level): rf_encode's = k_grid_forward<half,3,2>'s (gridencoder.hip), operation for operation -- the same bits.
+__global__ __launch_bounds__(256) void k_ft_encode_levels(rf_params P, const float* __restrict__ xyzs, uint32_t M, uint32_t Mp, uint32_t* __restrict__ enc) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mp) return;
+    const uint32_t level = blockIdx.y;
+    uint32_t out = 0u;                                                     // padding samples and samples outside the box encode to zeros
+    if (m < M) {
+        float x[3];
+        rf_normalise(P, xyzs[3ull * m], xyzs[3ull * m + 1], xyzs[3ull * m + 2], x[0], x[1], x[2]);
+        const bool oob = (x[0] < 0 || x[0] > 1) || (x[1] < 0 || x[1] > 1) || (x[2] < 0 || x[2] > 1);
+        if (!oob) {
+            const uint32_t o0 = (uint32_t)P.offsets[level], size = (uint32_t)P.offsets[level + 1] - o0;
+            const float scale = P.scale[level];
+            const uint32_t side = P.resolution[level] + 1u;
+            // get_grid_index (gridencoder.cu:54-72): strides grow while they fit; a level whose last stride does not fit is hashed
+            uint32_t stride = 1, s1 = 0, s2 = 0;
+            #pragma unroll
+            for (int d = 0; d < 3; d++)
+                if (stride <= size) { if (d == 1) s1 = stride; if (d == 2) s2 = stride; stride *= side; }
+            const bool dense = stride <= size;
+            const bool pow2 = (size & (size - 1u)) == 0u;
+            float f[3];
+            uint32_t pg[3];
+            #pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float p = x[d] * scale + 0.5f;
+                const float fl = floorf(p);
+                pg[d] = (uint32_t)fl;
+                f[d] = p - fl;
+            }
+            const uint32_t* tab = P.table + o0;
+            uint32_t raw[8];
+            if (dense) {                                                   // x + y s1 + z s2 < size by construction
+                const uint32_t i0 = pg[0] + pg[1] * s1 + pg[2] * s2;
+                #pragma unroll
+                for (int c = 0; c < 8; c++) raw[c] = tab[i0 + (c & 1) + ((c & 2) ? s1 : 0u) + ((c & 4) ? s2 : 0u)];
+            } else {
+                constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;      // fast_hash (gridencoder.cu:35-51)
+                const uint32_t hy[2] = {pg[1] * P1, (pg[1] + 1u) * P1}, hz[2] = {pg[2] * P2, (pg[2] + 1u) * P2};
+                #pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const uint32_t h = (pg[0] + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[c >> 2];
+                    raw[c] = tab[pow2 ? (h & (size - 1u)) : (h % size)];
+                }
+            }
+            // w = (wx * wy) * wz; acc = half(float(acc) + float(half(w * float(v)))) in the reference's corner order (gridencoder.cu:147-166)
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 acc = {(_Float16)0.0f, (_Float16)0.0f};
+            #pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float w = (((c & 1) ? f[0] : 1 - f[0]) * ((c & 2) ? f[1] : 1 - f[1])) * ((c & 4) ? f[2] : 1 - f[2]);
+                const h2 v = __builtin_bit_cast(h2, raw[c]);
+                const h2 prod = {ngp_f2h(w * (float)v.x), ngp_f2h(w * (float)v.y)};
+                acc = acc + prod;
+            }
+            out = __builtin_bit_cast(uint32_t, acc);
+        }
+    }
+    enc[(size_t)level * Mp + m] = out;
+}
+
 template <bool FIXED>
 __device__ __forceinline__ void ft_train_forward_loop(const rf_params& P, const rf_iter_class cls_rt, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w,
                                                       const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
-                                                      float* __restrict__ sigmas, float* __restrict__ rgbs, ngp_h8* __restrict__ enc) {
+                                                      float* __restrict__ sigmas, float* __restrict__ rgbs, uint32_t* __restrict__ enc, bool encoded) {
     const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
     const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
-    const uint32_t npairs = (M + 31) >> 5;
+    const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
     for (uint32_t pair = wave; pair < npairs; pair += nwaves) {
         ngp_h8 x[2];
         ngp_h4 shq[2];
@@ -151,8 +234,11 @@ __device__ __forceinline__ void ft_train_forward_loop(const rf_params& P, const 
                 if (g == 3) v = sh[12 + j];
                 shq[n][j] = ngp_f2h(v);
             }
-            x[n] = rf_encode<false>(P, lv, cls, px, py, pz);
-            enc[(size_t)(pair * 2 + n) * 64 + lane] = x[n];        // tiles are padded to pairs: the buffer holds 2 * npairs tiles
+            if (encoded) x[n] = ft_enc_load(enc, Mp, m[n], g);     // pass 2 of the two-pass forward: k_ft_encode_levels has filled the buffer (wave-uniform choice)
+            else {
+                x[n] = rf_encode<false>(P, lv, cls, px, py, pz);
+                ft_enc_store(enc, Mp, m[n], g, x[n]);              // the buffer is padded to whole pairs of tiles
+            }
         }
         float sg[2], cr[2], cg[2], cb[2];
         rv_mlp_tiles<2>(lds_w, lane, x, shq, sg, cr, cg, cb);
@@ -171,7 +257,7 @@ __device__ __forceinline__ void ft_train_forward_loop(const rf_params& P, const 
 #endif
 __global__ __launch_bounds__(RF_BLOCK, FT_FWD_WG_PER_CU) void k_field_train_forward(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
                                                                       uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs,
-                                                                      ngp_h8* __restrict__ enc) {
+                                                                      uint32_t* __restrict__ enc, bool encoded) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rf_smem);
     const int lane = threadIdx.x & 63, g = lane >> 4, wave = threadIdx.x >> 6;
@@ -180,8 +266,8 @@ __global__ __launch_bounds__(RF_BLOCK, FT_FWD_WG_PER_CU) void k_field_train_forw
     rf_setup_levels(P, g, lv);
     __syncthreads();
     const rf_iter_class cls = rf_classify(lv);
-    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u) ft_train_forward_loop<true>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs, enc);
-    else ft_train_forward_loop<false>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs, enc);
+    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u) ft_train_forward_loop<true>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs, enc, encoded);
+    else ft_train_forward_loop<false>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs, enc, encoded);
 }
 
 // NT = 2 tiles through the networks, every hidden activation kept (B fragments), plus the raw outputs.  COLOR = false stops after the
@@ -288,7 +374,7 @@ static constexpr int FT_A_SOUT = 0, FT_A_SHID = 4, FT_A_SIN = 20, FT_NACC_SIGMA 
                           ft_transposed(X[0][c1], X[1][c1], sel_p0), ft_transposed(X[0][c1], X[1][c1], sel_p1)}
 
 template <int PART>
-__global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params P, const ngp_h8* __restrict__ enc, const float* __restrict__ dirs, uint32_t M,
+__global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params P, const uint32_t* __restrict__ enc, const float* __restrict__ dirs, uint32_t M,
                                                                        const float* __restrict__ grad_sigmas, const float* __restrict__ grad_rgbs,
                                                                        ngp_h4* __restrict__ grad_outs, _Float16* __restrict__ grad_enc,
                                                                        float* __restrict__ wgrad_ws) {
@@ -329,7 +415,7 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
                     shq[n][j] = ngp_f2h(v);
                 }
             }
-            x[n] = enc[(size_t)(pair * 2 + n) * 64 + lane];
+            x[n] = ft_enc_load(enc, ((M + 31) >> 5) << 5, m[n], g);
         }
         ft_acts A;
         ft_recompute<PART == 0>(lds_w, lane, x, shq, A);
@@ -468,7 +554,9 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
         }
     }
 
-    // ---- the workgroup's weight gradients: sum the four waves through LDS, then one f32 atomic per element into the workspace ----
+    // ---- the workgroup's weight gradients: sum the four waves through LDS (fixed order), then this workgroup's row of the partial-sum buffer: plain
+    // stores, every element.  k_field_train_wgrad_finish adds the rows in a fixed order, so the gradients are bitwise reproducible (float atomics into
+    // one shared accumulator summed in arrival order: the fitted model's samples per ray moved by +-5 % from run to run) ----
     __syncthreads();                                               // every wave is done with the fragments
     float* lds_acc = reinterpret_cast<float*>(rf_smem);           // NACC x 256 f32 (44 KiB / 28 KiB)
     for (int w = 0; w < (int)(RF_BLOCK / 64); w++) {
@@ -498,24 +586,48 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
             else if (k < FT_A_SIN)   { base = FT_S_HID;  ld = 64; to = (k - FT_A_SHID) >> 2; ti = (k - FT_A_SHID) & 3; }
             else                     { base = FT_S_IN;   ld = 32; to = (k - FT_A_SIN) >> 1;  ti = (k - FT_A_SIN) & 1; }
         }
-        const float v = lds_acc[e];
-        if (v != 0.0f) unsafeAtomicAdd(wgrad_ws + base + (16 * to + 4 * gg + r) * ld + 16 * ti + ss, v);
+        wgrad_ws[(size_t)blockIdx.x * FT_WS_FLOATS + base + (16 * to + 4 * gg + r) * ld + 16 * ti + ss] = lds_acc[e];
     }
 }
 
-// workspace -> gradients of FFMLP.weights: rounded to half as the reference's grad_weights are, returned as float32; the workspace is cleared
-__global__ __launch_bounds__(256) void k_field_train_wgrad_finish(float* __restrict__ ws, float* __restrict__ grad_sigma_w, float* __restrict__ grad_color_w) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= FT_WS_FLOATS) return;
-    const float v = rf_h(ws[e]);
-    ws[e] = 0.0f;
-    if (e < 7168) grad_sigma_w[e] = v; else grad_color_w[e - 7168] = v;
+// partial sums [nblocks][FT_WS_FLOATS] -> gradients of FFMLP.weights: the rows added in a FIXED order (16 chunks of consecutive rows, each summed front to
+// back by one thread, then the 16 chunk sums front to back), rounded to half as the reference's grad_weights are, returned as float32.
+static constexpr uint32_t FT_FIN_COLS = 64, FT_FIN_CHUNKS = 16;
+__global__ __launch_bounds__(FT_FIN_COLS * FT_FIN_CHUNKS) void k_field_train_wgrad_finish(const float* __restrict__ ws, uint32_t nblocks, float* __restrict__ grad_sigma_w,
+                                                                                           float* __restrict__ grad_color_w) {
+    __shared__ float part[FT_FIN_CHUNKS][FT_FIN_COLS];
+    const uint32_t col = threadIdx.x % FT_FIN_COLS, chunk = threadIdx.x / FT_FIN_COLS;
+    const uint32_t e = blockIdx.x * FT_FIN_COLS + col;                     // FT_WS_FLOATS is a multiple of 64
+    const uint32_t per = (nblocks + FT_FIN_CHUNKS - 1) / FT_FIN_CHUNKS;
+    const uint32_t b0 = chunk * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    float sum = 0.0f;
+    for (uint32_t b = b0; b < b1; b++) sum += ws[(size_t)b * FT_WS_FLOATS + e];
+    part[chunk][col] = sum;
+    __syncthreads();
+    if (chunk == 0) {
+        float v = part[0][col];
+        #pragma unroll
+        for (uint32_t c = 1; c < FT_FIN_CHUNKS; c++) v += part[c][col];
+        v = rf_h(v);
+        if (e < 7168) grad_sigma_w[e] = v; else grad_color_w[e - 7168] = v;
+    }
 }
 
 extern "C" size_t ngp_field_train_saved_bytes(uint32_t M) { return (size_t)((M + 31) >> 5) * 2 * 64 * sizeof(ngp_h8); }
-// workspace: [f32 weight-gradient accumulators, kept zero between calls | the density-net output gradients of M samples]
-static size_t ft_ws_outs_offset() { return (FT_WS_FLOATS * sizeof(float) + 255) & ~(size_t)255; }
-extern "C" size_t ngp_field_train_workspace(uint32_t M) { return ft_ws_outs_offset() + (size_t)((M + 31) >> 5) * 2 * 64 * sizeof(ngp_h4); }
+// workgroups of the backward launches for M samples (persistent: at most one per CU), = rows of the partial-sum buffer
+static uint32_t ft_bwd_blocks(uint32_t M) {
+    const uint32_t blocks = ngp_div_up((M + 31) >> 5, RF_BLOCK / 64);
+    return blocks > 256 ? 256 : blocks;
+}
+// workspace: [per-workgroup f32 weight-gradient partial sums, ft_bwd_blocks(M) x 18,432 | the density-net output gradients of M samples]; nothing to clear
+static size_t ft_ws_outs_offset(uint32_t M) { return ((size_t)ft_bwd_blocks(M) * FT_WS_FLOATS * sizeof(float) + 255) & ~(size_t)255; }
+extern "C" size_t ngp_field_train_workspace(uint32_t M) { return ft_ws_outs_offset(M) + (size_t)((M + 31) >> 5) * 2 * 64 * sizeof(ngp_h4); }
+
+// The forward in two passes (k_ft_encode_levels, then the networks) or in one (the gather fused with the networks); same values, same kept buffer.
+// Process-wide switch for A/B timing and tests; batches below FT_TWO_PASS_MIN points are latency-bound either way and take the single launch.
+static std::atomic<int> ft_two_pass{1};
+static constexpr uint32_t FT_TWO_PASS_MIN = 65536;
+extern "C" int ngp_field_train_set_two_pass(int enabled) { return ft_two_pass.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int ngp_field_train_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
                                        float* sigmas, float* rgbs, void* saved, size_t saved_bytes, void* stream) {
@@ -526,10 +638,15 @@ extern "C" int ngp_field_train_forward(const ngp_field_t* field_host, const floa
     NGP_REQUIRE(xyzs && dirs && sigmas && rgbs && saved, "field_train_forward: null pointer");
     NGP_REQUIRE(saved_bytes >= ngp_field_train_saved_bytes(M), "field_train_forward: saved buffer too small (%zu < %zu bytes)", saved_bytes,
                 ngp_field_train_saved_bytes(M));
-    const uint32_t npairs = (M + 31) >> 5;
+    const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
     uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
     if (blocks > 256 * FT_FWD_WG_PER_CU) blocks = 256 * FT_FWD_WG_PER_CU;
-    hipLaunchKernelGGL(k_field_train_forward, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs, (ngp_h8*)saved);
+    const bool two_pass = ft_two_pass.load(std::memory_order_relaxed) != 0 && M >= FT_TWO_PASS_MIN;
+    if (two_pass) {
+        hipLaunchKernelGGL(k_ft_encode_levels, dim3(ngp_div_up(Mp, 256u), RF_L), dim3(256), 0, (hipStream_t)stream, P, xyzs, M, Mp, (uint32_t*)saved);
+        NGP_CHECK_LAUNCH("field_train_forward (encode)");
+    }
+    hipLaunchKernelGGL(k_field_train_forward, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs, (uint32_t*)saved, two_pass);
     NGP_CHECK_LAUNCH("field_train_forward");
     return NGP_OK;
 }
@@ -554,19 +671,18 @@ extern "C" int ngp_field_train_backward(const ngp_field_t* field_host, const voi
                         "field_train_backward: cannot reserve %u bytes of LDS", FT_LDS);
             ft_big_lds_set.fetch_or(1u << dev, std::memory_order_release);
         }
-        const uint32_t npairs = (M + 31) >> 5;
-        uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
-        if (blocks > 256) blocks = 256;
-        ngp_h4* grad_outs = reinterpret_cast<ngp_h4*>(static_cast<unsigned char*>(workspace) + ft_ws_outs_offset());
-        hipLaunchKernelGGL(k_field_train_backward<0>, dim3(blocks), dim3(RF_BLOCK), FT_LDS, (hipStream_t)stream, P, (const ngp_h8*)saved, dirs, M,
+        const uint32_t blocks = ft_bwd_blocks(M);
+        ngp_h4* grad_outs = reinterpret_cast<ngp_h4*>(static_cast<unsigned char*>(workspace) + ft_ws_outs_offset(M));
+        hipLaunchKernelGGL(k_field_train_backward<0>, dim3(blocks), dim3(RF_BLOCK), FT_LDS, (hipStream_t)stream, P, (const uint32_t*)saved, dirs, M,
                            grad_sigmas, grad_rgbs, grad_outs, (_Float16*)grad_enc, (float*)workspace);
         NGP_CHECK_LAUNCH("field_train_backward (colour net)");
-        hipLaunchKernelGGL(k_field_train_backward<1>, dim3(blocks), dim3(RF_BLOCK), FT_LDS, (hipStream_t)stream, P, (const ngp_h8*)saved, dirs, M,
+        hipLaunchKernelGGL(k_field_train_backward<1>, dim3(blocks), dim3(RF_BLOCK), FT_LDS, (hipStream_t)stream, P, (const uint32_t*)saved, dirs, M,
                            grad_sigmas, grad_rgbs, grad_outs, (_Float16*)grad_enc, (float*)workspace);
         NGP_CHECK_LAUNCH("field_train_backward (density net)");
     }
-    hipLaunchKernelGGL(k_field_train_wgrad_finish, dim3(ngp_div_up(FT_WS_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, (float*)workspace,
-                       grad_sigma_weights, grad_color_weights);
+    static_assert(FT_WS_FLOATS % FT_FIN_COLS == 0, "finish: whole column groups");
+    hipLaunchKernelGGL(k_field_train_wgrad_finish, dim3(FT_WS_FLOATS / FT_FIN_COLS), dim3(FT_FIN_COLS * FT_FIN_CHUNKS), 0, (hipStream_t)stream, (const float*)workspace,
+                       M > 0 ? ft_bwd_blocks(M) : 0u, grad_sigma_weights, grad_color_weights);
     NGP_CHECK_LAUNCH("field_train_wgrad_finish");
     return NGP_OK;
 }

@@ -17,3 +17,9 @@ size_t ffmlp_generic_backward_workspace(uint32_t input_dim, uint32_t output_dim,
 int ffmlp_generic_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B, uint32_t input_dim,
                            uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, int calc_grad_inputs,
                            void* backward_buffer, void* grad_inputs, void* grad_weights, void* workspace, size_t workspace_bytes, hipStream_t s);
+
+// Weight gradients without float atomics (bitwise reproducible): workgroup column x of a weight-gradient launch stores its partial sums as row x of a
+// [rows][nw] f32 buffer at the head of the workspace; ffmlp_sum_partials adds the rows in a fixed order and rounds to half.
+uint32_t ffmlp_partial_rows(uint32_t nw);                                  // rows the workspace holds (<= 256, <= 64 MiB of partials)
+size_t ffmlp_partial_bytes(uint32_t nw);                                   // the buffer's size, 256-byte aligned
+void ffmlp_sum_partials(const float* partials, uint32_t rows, uint32_t nw, void* grad_weights_half, hipStream_t s);

@@ -123,6 +123,16 @@ __device__ __forceinline__ rf_row2 rf_rows(const rf_params& P, uint32_t byte_off
 // issue the next tile's pair 1 (the hashed levels, the slow gathers) before the current tile's MLP (RV_PIPELINE).
 struct rf_pair { uint32_t raw[2][8]; float fx[2], fy[2], fz[2]; };
 
+#ifndef RF_PAIR_HASHED
+#define RF_PAIR_HASHED 0               // 1: on hashed levels an even-x lane fetches both x-corners with ONE aligned 8-byte load; A/B: HISTORY 4
+#endif
+__device__ __forceinline__ rf_row2 rf_rows8(const rf_params& P, uint32_t byte_off) {      // one 8-byte load, 8-byte aligned
+    asm("" : "+v"(byte_off));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 v = *reinterpret_cast<const u2*>(reinterpret_cast<const char*>(P.table) + byte_off);
+    return rf_row2{v.x, v.y};
+}
+
 __device__ __forceinline__ void rf_normalise(const rf_params& P, float wx, float wy, float wz, float& x0, float& x1, float& x2) {
     // GridEncoder.forward (grid.py:144): (x + bound) / (2 bound) -- as torch evaluates it on the GPU: a tensor divided by a host scalar is the
     // product with the scalar's binary32 reciprocal (ATen BinaryDivTrueKernel.cu: "compute a * reciprocal(b)").  For a power-of-two 2 * bound
@@ -172,6 +182,30 @@ __device__ __forceinline__ void rf_gather_pair(const rf_params& P, const rf_lane
                 const uint32_t hy1 = hy + (P1 << 2), hz1 = hz + (P2 << 2);
                 const uint32_t a0 = (gx << 2) & m, a1 = ((gx << 2) + 4u) & m;
                 const uint32_t yz0 = (hy ^ hz) & m, yz1 = (hy1 ^ hz) & m, yz2 = (hy ^ hz1) & m, yz3 = (hy1 ^ hz1) & m;
+#if RF_PAIR_HASHED
+                // The x-neighbour of a hashed corner: fast_hash xors x * 1 into the index (gridencoder.cu:35-51), so for an EVEN cell coordinate
+                // index(x + 1, y, z) = index(x, y, z) ^ 1 (2^k rows, k >= 1: the mask keeps bit 0): both rows lie in one aligned 8-byte word and ONE
+                // load serves both corners -- which half is which depends on bit 0 of the (y, z) hash.  Lanes with an odd x fetch their second
+                // corner with a load of their own, the even lanes masked off: the texture path is busy per lane address (HISTORY 1), and these
+                // levels go from 8 to 6 of them per sample on average.  Same rows, same bits.
+                {
+                    const uint32_t yz[4] = {yz0, yz1, yz2, yz3};
+                    const bool odd = (gx & 1u) != 0u;
+                    #pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t A = a0 ^ yz[k];                                 // byte offset of corner (x, y, z) inside the level
+                        const rf_row2 r = rf_rows8(P, (A & ~4u) + b);
+                        const bool hi = (A & 4u) != 0u;
+                        raw[i & 1][2 * k] = hi ? r.hi : r.lo;
+                        raw[i & 1][2 * k + 1] = hi ? r.lo : r.hi;                      // row A ^ 4: corner (x + 1, y, z) when x is even
+                    }
+                    if (odd) {
+                        #pragma unroll
+                        for (int k = 0; k < 4; k++) raw[i & 1][2 * k + 1] = rf_row(P, (a1 ^ yz[k]) + b);
+                    }
+                    continue;
+                }
+#endif
                 off[0] = (a0 ^ yz0) + b; off[1] = (a1 ^ yz0) + b; off[2] = (a0 ^ yz1) + b; off[3] = (a1 ^ yz1) + b;
                 off[4] = (a0 ^ yz2) + b; off[5] = (a1 ^ yz2) + b; off[6] = (a0 ^ yz3) + b; off[7] = (a1 ^ yz3) + b;
 #ifdef RV_EXPERIMENT_WINDOW        // timing-only build: levels 8..15 gather inside a window of this many bytes per level

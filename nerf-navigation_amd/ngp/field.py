@@ -94,10 +94,7 @@ class _field_train(Function):
         grad_enc = torch.empty(enc.num_levels, M, enc.level_dim, dtype=torch.float16, device=x.device)
         g_ws = torch.empty(ws_half.numel(), dtype=torch.float32, device=x.device)
         g_wc = torch.empty(wc_half.numel(), dtype=torch.float32, device=x.device)
-        work = getattr(ctx, "cleared_work", None)          # (ngp/train.py's direct step allocates it early and clears its header in the loss-head launch)
-        if work is None:
-            work = _hip.workspace(L.ngp_field_train_workspace(M), x.device)
-            work[:L.ngp_field_train_workspace(0)].zero_()
+        work = _hip.workspace(L.ngp_field_train_workspace(M), x.device)      # per-workgroup partial sums of the weight gradients: nothing to clear
         with _hip.timed("field_train_backward"):
             _hip.check(L.ngp_field_train_backward(ctypes.byref(ctx.fstruct), _hip.ptr(saved), _hip.ptr(d), M, _hip.ptr(g_sig), _hip.ptr(g_rgb),
                                                   _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), _hip.stream()),

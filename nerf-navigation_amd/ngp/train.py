@@ -386,7 +386,7 @@ class NGPTrainer:
         c_comp = _Ctx((True, True, False, False))
         weights_sum, depth, image = _body(RM._composite_rays_train.forward)(c_comp, ren.density_scale * sigmas if scale_sigma else sigmas, rgbs, deltas, rays)
         # background mix, loss, and the loss's backward down to the compositor's two incoming gradients in ONE launch (the values of _mix_background and
-        # _mse_head run forward and backward, bit for bit); the same launch clears what the next two backward launches expect zeroed
+        # _mse_head run forward and backward, bit for bit); the same launch clears what the compositor's backward expects zeroed
         import ngp_hip as _hip
         L, dev, M, N = _hip.lib(), image.device, xyzs.shape[0], weights_sum.shape[0]
         mixed = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -394,11 +394,10 @@ class NGPTrainer:
         g_image, g_ws = torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)
         sig_in = c_comp.saved_tensors[0]
         g_sig, g_rgb = torch.empty_like(sig_in), torch.empty(sig_in.shape[0], 3, dtype=torch.float32, device=dev)
-        work = _hip.workspace(L.ngp_field_train_workspace(M), dev)
-        clear = [(g_sig, g_sig.numel() * 4), (g_rgb, g_rgb.numel() * 4), (work, int(L.ngp_field_train_workspace(0)))]
+        clear = [(g_sig, g_sig.numel() * 4), (g_rgb, g_rgb.numel() * 4)]
         clear = [(t, b) for t, b in clear if b > 0 and t.data_ptr() % 16 == 0 and b % 16 == 0]
-        if len(clear) < 3:                           # (an empty batch, or a size that is not a multiple of 16 bytes: the torch fills)
-            g_sig.zero_(); g_rgb.zero_(); work[:L.ngp_field_train_workspace(0)].zero_()
+        if len(clear) < 2:                           # (an empty batch, or a size that is not a multiple of 16 bytes: the torch fills)
+            g_sig.zero_(); g_rgb.zero_()
             clear = []
         ws_head = _mse_head._ws.get(dev)
         if ws_head is None:
@@ -413,7 +412,6 @@ class NGPTrainer:
         # ---- the rest of the backward, in the engine's order ----
         c_comp.cleared_grads = (g_sig, g_rgb)
         g_sig, g_rgb, _, _ = _body(RM._composite_rays_train.backward)(c_comp, g_ws, None, g_image)
-        c_field.cleared_work = work
         if scale_sigma:
             g_sig = g_sig * ren.density_scale
         grads = _body(_field_train.backward)(c_field, g_sig, g_rgb)

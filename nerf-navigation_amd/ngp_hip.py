@@ -85,6 +85,7 @@ _SIGNATURES = {
     "ngp_field_train_backward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_render_frame_workspace": (c_sz, [c_u32]),
     "ngp_render_set_block_skip": (c_int, [c_int]),
+    "ngp_field_train_set_two_pass": (c_int, [c_int]),
     "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_grid_encode_backward_inputs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_vp, c_u32, c_int, c_int, c_vp]),
@@ -203,6 +204,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = _GuardedLib(handle)
+        if os.environ.get("NGP_FT_TWO_PASS") in ("0", "1"):              # A/B switch of the training forward (tools, bench.py --mode train); default: two passes
+            handle.ngp_field_train_set_two_pass(int(os.environ["NGP_FT_TWO_PASS"]))
     return _lib
 
 

@@ -17,9 +17,13 @@ __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", 
 
 
 def _rays(t):
-    """[..., 3] -> contiguous [N, 3] on the GPU (the reference moves CPU inputs over: raymarching.py:34-35)."""
+    """[..., 3] -> contiguous float32 [N, 3] on the GPU (the reference moves CPU inputs over: raymarching.py:34-35).  The kernels read float32:
+    custom_fwd(cast_inputs=float32) converts half / bfloat16 inputs under autocast but never float64 ones (torch.amp's cast skips them) and nothing
+    outside autocast, where the reference would hand the kernel another dtype's bytes; here any other floating dtype is converted."""
     if not t.is_cuda:
         t = t.cuda()
+    if t.dtype != torch.float32:
+        t = t.float()
     return t.contiguous().view(-1, 3)
 
 

@@ -273,7 +273,7 @@ def test_native_adam_at_the_field_s_full_size(dev):
 
 
 def test_a_step_with_float64_directions_or_a_short_target_does_not_reach_the_direct_kernels(dev):
-    """float64 rays_d trains like float32 rays_d (cast by the autograd route's custom_fwd, as in the reference's wrappers); a target with fewer colours than
+    """float64 rays_d trains like float32 rays_d (the ray wrappers convert any floating dtype; torch.amp never casts float64); a target with fewer colours than
     rays raises instead of being read past its end"""
     from ngp import workload as W
     from ngp.field import NGPFieldFF
@@ -311,3 +311,38 @@ def test_a_field_with_more_tensors_than_the_native_launch_takes_keeps_torch_adam
     to, td = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
     loss = tr.step(to, td, torch.rand(1, 256, 3, device=dev), bg_color=1, max_steps=64)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("direct", [True, False], ids=["direct_step", "autograd_step"])
+def test_two_runs_of_the_same_training_are_bit_identical(dev, direct):
+    """no float atomic is left in the training step -- the table gradient is an exact fixed-point sum (csrc/gridencoder.hip), the 18,432
+    weight gradients are per-workgroup partial sums added in a fixed order (csrc/field_train.hip, ffmlp_backward.hip) -- so the same seed gives the same
+    bits: every loss, every parameter, the occupancy grid and the sample counters, over a run that crosses several grid refreshes"""
+    a, tra, la, _ = _trained(dev, True, steps=72, direct=direct)
+    b, trb, lb, _ = _trained(dev, True, steps=72, direct=direct)
+    assert la == lb
+    for pa, pb in zip(a.field.parameters(), b.field.parameters()):
+        assert torch.equal(pa, pb)
+    assert torch.equal(a.density_grid, b.density_grid) and torch.equal(a.density_bitfield, b.density_bitfield)
+    assert torch.equal(a.step_counter, b.step_counter) and a.mean_count == b.mean_count
+    for sa, sb in zip(tra.ema.shadow, trb.ema.shadow):
+        assert torch.equal(sa, sb)
+
+
+def test_ffmlp_weight_gradients_are_bit_reproducible(dev):
+    """the op-by-op FFMLP (ffmlp.FFMLP, the drop-in of ffmlp/ffmlp.py:100-168): two backward passes over the same batch return the same bits, for the
+    register-resident kernels (width 64) and the layer-by-layer ones (width 128)"""
+    from ffmlp import FFMLP
+    for hidden, layers in ((64, 3), (128, 2)):
+        torch.manual_seed(3)
+        net = FFMLP(32, 16, hidden, layers).to(dev)
+        x = torch.randn(40000, 32, device=dev)
+        g = torch.randn(40000, 16, device=dev)
+        grads = []
+        for _ in range(3):
+            net.weights.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = net(x)
+            y.backward(g.to(y.dtype))
+            grads.append(net.weights.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]) and grads[0].abs().max() > 0

@@ -98,3 +98,29 @@ def test_fused_training_with_an_empty_batch_and_a_non_power_of_two_bound(dev):
     assert float(((got[0] - ref[0]).abs() / ref[0]).max()) < 2e-3 and float((got[0] != ref[0]).float().mean()) < 0.05
     for a, b in zip(got[2:], ref[2:]):
         assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("M", [70000, 200001])
+def test_two_pass_forward_equals_the_one_launch_forward_bit_for_bit(dev, M):
+    """the training forward encodes level by level (k_ft_encode_levels: one level's table live in L2 at a time) and runs the networks
+    in a second pass.  Same arithmetic per (sample, level) as the fused gather: sigma, rgb, the kept features (through the gradients they produce) and
+    every gradient are the same BITS as with the single launch -- and the whole step is bitwise reproducible (no atomics: exact table sums, fixed-order
+    weight-gradient sums)."""
+    import ngp_hip
+    field, W = _field(dev)
+    field.train()
+    x, d, gs, gc = _points(W, M, dev, seed=M)
+    x[::3] *= 0.2                                                      # a third of the points near the centre: the dense and the hashed levels see runs and collisions
+    L = ngp_hip.lib()
+    try:
+        assert L.ngp_field_train_set_two_pass(0) == 1                  # (two passes are the default)
+        one = _step(field, True, x, d, gs, gc, 1.0)
+        L.ngp_field_train_set_two_pass(1)
+        two = _step(field, True, x, d, gs, gc, 1.0)
+        again = _step(field, True, x, d, gs, gc, 1.0)
+    finally:
+        L.ngp_field_train_set_two_pass(1)
+    for name, a, b, c in zip(["sigma", "rgb", "table gradient", "density-net weight gradient", "colour-net weight gradient"], one, two, again):
+        assert torch.equal(a, b), name
+        assert torch.equal(b, c), name + " (second run)"
+    assert float(two[2].abs().max()) > 0 and float(two[3].abs().max()) > 0
