@@ -366,6 +366,9 @@ typedef struct {
  * autocast.  xyzs, dirs [M,3] f32; sigmas [M] f32 (already times density_scale); rgbs [M,3] f32. */
 int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
                       float* sigmas, float* rgbs, void* stream);
+/* the same, rgbs [M,3] written as f16: the dtype the reference's network_ff returns under autocast (the values are halves either way) */
+int ngp_field_forward_half(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
+                           float* sigmas, void* rgbs_half, void* stream);
 
 /* The field's training step in two calls: NeRFNetwork.forward (nerf/network_ff.py:51-77) under autocast and the backward autograd
  * runs through it (ffmlp/src/ffmlp.cu:410-518,749-895; activation.py:17-21; torch.sigmoid), for the default field shapes.

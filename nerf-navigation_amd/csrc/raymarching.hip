@@ -1002,38 +1002,36 @@ __global__ __launch_bounds__(RM_BLOCK) void k_compact_count(const int* __restric
     if (threadIdx.x == 0) block_sums[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-__global__ __launch_bounds__(RM_BLOCK) void k_compact_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks, int* __restrict__ n_out) {
-    __shared__ uint32_t lds4[RM_BLOCK / 64];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t i0 = 0; i0 < nblocks; i0 += RM_BLOCK) {
-        const uint32_t i = i0 + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
-        uint32_t total;
-        const uint32_t inc = block_inclusive_scan<RM_BLOCK / 64>(v, lds4, total);
-        const uint32_t c = carry;
-        if (i < nblocks) block_sums[i] = c + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) n_out[0] = (int)carry;
-}
-
+// Stable compaction in TWO launches (count, then write): every workgroup of the write pass adds up the counts of the workgroups before it itself
+// (<= 2,500 L2-resident words for an 800 x 800 frame, 256 lanes at a time) instead of waiting for a one-workgroup scan launch in between -- the loop
+// runs this once per iteration, ~66 times per frame, and every launch is ~5 us on its critical path.  The last workgroup also publishes the total.
 __global__ __launch_bounds__(RM_BLOCK) void k_compact_write(const int* __restrict__ rays_alive, uint32_t n_alive,
-                                                            const uint32_t* __restrict__ block_sums, int* __restrict__ out) {
-    __shared__ uint32_t lds4[RM_BLOCK / 64];
+                                                            const uint32_t* __restrict__ block_sums, int* __restrict__ out, int* __restrict__ n_out) {
+    __shared__ uint32_t lds4[RM_BLOCK / 64], lds_base[RM_BLOCK / 64];
     const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
     const int v = (n < n_alive) ? rays_alive[n] : -1;
     const bool keep = v >= 0;
     const unsigned long long mask = __ballot(keep);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) lds4[wave] = (uint32_t)__popcll(mask);
+    uint32_t before = 0;                                                   // kept rays in the workgroups before this one
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += RM_BLOCK) before += block_sums[i];
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+    if (lane == 0) { lds4[wave] = (uint32_t)__popcll(mask); lds_base[wave] = before; }
     __syncthreads();
-    uint32_t base = block_sums[blockIdx.x];
-    for (uint32_t w = 0; w < wave; w++) base += lds4[w];
+    uint32_t base = 0;
+    #pragma unroll
+    for (uint32_t w = 0; w < RM_BLOCK / 64; w++) base += lds_base[w];
+    uint32_t mine = 0;
+    #pragma unroll
+    for (uint32_t w = 0; w < RM_BLOCK / 64; w++) { if (w < wave) base += lds4[w]; mine += lds4[w]; }
     if (keep) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint32_t total = 0;
+        #pragma unroll
+        for (uint32_t w = 0; w < RM_BLOCK / 64; w++) total += lds_base[w];
+        n_out[0] = (int)(total + mine);
+    }
 }
 
 extern "C" size_t ngp_compact_alive_workspace(uint32_t n_alive) {
@@ -1048,8 +1046,7 @@ extern "C" int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, in
     const uint32_t nblocks = ngp_div_up(n_alive ? n_alive : 1, RM_BLOCK);
     uint32_t* block_sums = (uint32_t*)workspace;
     hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums);
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, n_out);
-    hipLaunchKernelGGL(k_compact_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums, out);
+    hipLaunchKernelGGL(k_compact_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums, out, n_out);
     NGP_CHECK_LAUNCH("compact_alive");
     return NGP_OK;
 }

@@ -31,11 +31,9 @@
 #include "ngp_camera.h"
 
 __global__ void k_field_forward_lds(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
-                                    float* __restrict__ sigmas, float* __restrict__ rgbs);
+                                    float* __restrict__ sigmas, void* __restrict__ rgbs, bool rgb_half);
 
-
-extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
-                                 float* sigmas, float* rgbs, void* stream) {
+static int rf_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, void* rgbs, bool rgb_half, void* stream) {
     rf_params P;
     int rc = rf_fill_params("field_forward", field_host, P);
     if (rc != NGP_OK) return rc;
@@ -44,9 +42,21 @@ extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyz
     const uint32_t npairs = (M + 31) >> 5;
     uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
     if (blocks > 256 * RF_FIELD_WG_PER_CU) blocks = 256 * RF_FIELD_WG_PER_CU;
-    hipLaunchKernelGGL(k_field_forward_lds, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs);
+    hipLaunchKernelGGL(k_field_forward_lds, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs, rgb_half);
     NGP_CHECK_LAUNCH("field_forward");
     return NGP_OK;
+}
+
+extern "C" int ngp_field_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
+                                 float* sigmas, float* rgbs, void* stream) {
+    return rf_field_forward(field_host, xyzs, dirs, M, sigmas, rgbs, false, stream);
+}
+
+// The same with rgbs [M,3] written as HALF -- the dtype nerf/network_ff.py:51-77 returns under autocast (torch.sigmoid of FFMLP's half output); the values are
+// halves either way.  Saves the caller's float32 -> float16 copy launch per loop iteration (profiles/r16_dropin_summary.md).
+extern "C" int ngp_field_forward_half(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
+                                      float* sigmas, void* rgbs_half, void* stream) {
+    return rf_field_forward(field_host, xyzs, dirs, M, sigmas, rgbs_half, true, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -273,7 +283,7 @@ __device__ __forceinline__ bool rv_probe(const rv_ray& ray, const rv_consts& k, 
 template <bool FIXED>
 __device__ __forceinline__ void rf_points_loop(const rf_params& P, const rf_iter_class cls_rt, const rf_lane_levels& lv, const ngp_h8* __restrict__ lds_w,
                                                const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
-                                               float* __restrict__ sigmas, float* __restrict__ rgbs) {
+                                               float* __restrict__ sigmas, void* __restrict__ rgbs_v, bool rgb_half) {
     const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
     const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
@@ -306,13 +316,19 @@ __device__ __forceinline__ void rf_points_loop(const rf_params& P, const rf_iter
             if (g == 0 && m[n] < M) {
                 rv_activate(P, sg[n], cr[n], cg[n], cb[n]);
                 sigmas[m[n]] = sg[n];
-                rgbs[3ull * m[n]] = cr[n]; rgbs[3ull * m[n] + 1] = cg[n]; rgbs[3ull * m[n] + 2] = cb[n];
+                if (rgb_half) {                                // (wave-uniform) the colours ARE halves: rv_activate rounded them
+                    _Float16* rgbs = static_cast<_Float16*>(rgbs_v);
+                    rgbs[3ull * m[n]] = (_Float16)cr[n]; rgbs[3ull * m[n] + 1] = (_Float16)cg[n]; rgbs[3ull * m[n] + 2] = (_Float16)cb[n];
+                } else {
+                    float* rgbs = static_cast<float*>(rgbs_v);
+                    rgbs[3ull * m[n]] = cr[n]; rgbs[3ull * m[n] + 1] = cg[n]; rgbs[3ull * m[n] + 2] = cb[n];
+                }
             }
     }
 }
 
 __global__ __launch_bounds__(RF_BLOCK, RF_FIELD_WG_PER_CU) void k_field_forward_lds(rf_params P, const float* __restrict__ xyzs, const float* __restrict__ dirs,
-                                                                    uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs) {
+                                                                    uint32_t M, float* __restrict__ sigmas, void* __restrict__ rgbs, bool rgb_half) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rf_smem);
     const int lane = threadIdx.x & 63, g = lane >> 4, wave = threadIdx.x >> 6;
@@ -321,8 +337,8 @@ __global__ __launch_bounds__(RF_BLOCK, RF_FIELD_WG_PER_CU) void k_field_forward_
     rf_setup_levels(P, g, lv);
     __syncthreads();
     const rf_iter_class cls = rf_classify(lv);
-    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u) rf_points_loop<true>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs);
-    else rf_points_loop<false>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs);
+    if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u) rf_points_loop<true>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs, rgb_half);
+    else rf_points_loop<false>(P, cls, lv, lds_w, xyzs, dirs, M, sigmas, rgbs, rgb_half);
 }
 
 // queue index -> ray id.  With tile_w set (rays are a row-major image whose width and height are multiples of 8)

@@ -219,8 +219,7 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         if self._fused_training_applies(x, d):
             return _field_train.apply(x, d, self.encoder.embeddings, self.sigma_net.weights, self.color_net.weights, self)
         if self._fused_inference_applies(x, d):
-            sigma, rgb = self.forward_fused(x, d, density_scale=1.0)
-            return sigma, rgb.to(torch.float16)      # (the values are halves already)
+            return self.forward_fused(x, d, density_scale=1.0, rgb_dtype=torch.float16)     # rgb half, like torch.sigmoid of FFMLP's half output
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])
@@ -349,15 +348,17 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
             emb_p._ngp_half = None
 
     @torch.no_grad()
-    def forward_fused(self, x, d, density_scale=None):
-        """sigma (already times density_scale) and rgb for [M,3] points / directions in one launch (float32 out)."""
+    def forward_fused(self, x, d, density_scale=None, rgb_dtype=torch.float32):
+        """sigma (already times density_scale) and rgb for [M,3] points / directions in one launch (sigma float32; rgb float32, or float16 written by
+        the kernel itself: the values are halves either way)."""
         x, d = x.contiguous().float(), d.contiguous().float()
         M = x.shape[0]
         sig = torch.empty(M, dtype=torch.float32, device=x.device)
-        rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        rgb = torch.empty(M, 3, dtype=rgb_dtype, device=x.device)
         f = self.fused_state(density_scale)
-        _hip.check(_hip.lib().ngp_field_forward(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb),
-                                                _hip.stream()), "field_forward")
+        L = _hip.lib()
+        entry = L.ngp_field_forward_half if rgb_dtype == torch.float16 else L.ngp_field_forward
+        _hip.check(entry(ctypes.byref(f), _hip.ptr(x), _hip.ptr(d), M, _hip.ptr(sig), _hip.ptr(rgb), _hip.stream()), "field_forward")
         return sig, rgb
 
 

@@ -6,11 +6,41 @@ behaviour as the reference (file:line cited per function).  Differences, all sup
   * kernels run on torch's current HIP stream (the reference used the legacy default stream);
   * march_rays_train allocates slots in ray order (deterministic) instead of atomic arrival order.
 """
+import functools
+
 import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
 import ngp_hip as _hip
+
+
+def _f32_forward(fwd):
+    """`custom_fwd(device_type="cuda", cast_inputs=torch.float32)` for a Function that has NO backward: under autocast the half / bfloat16 CUDA tensor
+    arguments are converted to float32, exactly the set torch.amp casts.  The stock decorator walks every argument through a recursive `_cast` and
+    enters an `autocast(enabled=False)` context: ~25 us of host time per call, three calls per iteration of the inference loop, on the critical path right
+    after that loop's one synchronisation (profiles/r16_dropin_summary.md).  The bodies below call native code only, so there is nothing for a disabled
+    autocast to protect, and without a backward nothing reads `ctx._fwd_used_autocast`."""
+    @functools.wraps(fwd)
+    def wrapper(ctx, *args):
+        if torch.is_autocast_enabled("cuda"):
+            args = tuple(a.float() if (isinstance(a, torch.Tensor) and a.is_cuda and (a.dtype == torch.float16 or a.dtype == torch.bfloat16)) else a
+                         for a in args)
+        return fwd(ctx, *args)
+    return wrapper
+
+
+def _public(fn_cls):
+    """the package-level callable of a forward-only Function: `Function.apply` when autograd is recording (so that differentiating through it fails as in
+    the reference), the forward body itself under no_grad (inference loops: ~10 us of autograd bookkeeping per call saved)"""
+    apply, fwd = fn_cls.apply, fn_cls.forward
+
+    @functools.wraps(fwd)
+    def call(*args):
+        if torch.is_grad_enabled():
+            return apply(*args)
+        return fwd(None, *args)
+    return call
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "composite_rays", "compact_alive"]
@@ -31,7 +61,7 @@ class _near_far_from_aabb(Function):
     """reference: raymarching/raymarching.py:19-49"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_f32_forward
     def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
         aabb = aabb.to(rays_o.device).contiguous()
@@ -43,14 +73,14 @@ class _near_far_from_aabb(Function):
         return nears, fars
 
 
-near_far_from_aabb = _near_far_from_aabb.apply
+near_far_from_aabb = _public(_near_far_from_aabb)
 
 
 class _sph_from_ray(Function):
     """reference: raymarching/raymarching.py:52-80"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_f32_forward
     def forward(ctx, rays_o, rays_d, radius):
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
         N = rays_o.shape[0]
@@ -60,7 +90,7 @@ class _sph_from_ray(Function):
         return coords
 
 
-sph_from_ray = _sph_from_ray.apply
+sph_from_ray = _public(_sph_from_ray)
 
 
 class _morton3D(Function):
@@ -77,7 +107,7 @@ class _morton3D(Function):
         return indices
 
 
-morton3D = _morton3D.apply
+morton3D = _public(_morton3D)
 
 
 class _morton3D_invert(Function):
@@ -94,14 +124,14 @@ class _morton3D_invert(Function):
         return coords
 
 
-morton3D_invert = _morton3D_invert.apply
+morton3D_invert = _public(_morton3D_invert)
 
 
 class _packbits(Function):
     """reference: raymarching/raymarching.py:129-153 (writes into `bitfield` when given)"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_f32_forward
     def forward(ctx, grid, thresh, bitfield=None):
         if not grid.is_cuda:
             grid = grid.cuda()
@@ -114,14 +144,14 @@ class _packbits(Function):
         return bitfield
 
 
-packbits = _packbits.apply
+packbits = _public(_packbits)
 
 
 class _march_rays_train(Function):
     """reference: raymarching/raymarching.py:161-228 (same M / mean_count / align logic, same D2H read of the counter)"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_f32_forward
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
                 perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
@@ -209,7 +239,7 @@ class _march_rays(Function):
     """reference: raymarching/raymarching.py:292-335 (M padded past the next multiple of `align`)"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_f32_forward
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
                 align=-1, perturb=False, dt_gamma=0, max_steps=1024):
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
@@ -231,14 +261,14 @@ class _march_rays(Function):
         return xyzs, dirs, deltas
 
 
-march_rays = _march_rays.apply
+march_rays = _public(_march_rays)
 
 
 class _composite_rays(Function):
     """reference: raymarching/raymarching.py:340-359 (returns an empty tuple; mutates its arguments in place)"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @_f32_forward
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
         _hip.check(_hip.lib().ngp_composite_rays(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t),
                                                  _hip.ptr(sigmas.contiguous()), _hip.ptr(rgbs.contiguous()), _hip.ptr(deltas),
@@ -247,7 +277,7 @@ class _composite_rays(Function):
         return tuple()
 
 
-composite_rays = _composite_rays.apply
+composite_rays = _public(_composite_rays)
 
 
 def compact_alive(rays_alive, n_alive=None):

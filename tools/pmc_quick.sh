@@ -6,9 +6,9 @@ V=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp NGP_HIP_LIB=$R/build/var/libngp_$V.so
 cd /tmp
-timeout -k 10 150 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_a -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --frames-per-launch 1 > $R/gpurun_out/q_${V}_a.log 2>&1
-timeout -k 10 150 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --frames-per-launch 1 > $R/gpurun_out/q_${V}_c.log 2>&1
-timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_b -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --frames-per-launch 1 > $R/gpurun_out/q_${V}_b.log 2>&1
+timeout -k 10 150 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_a -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --no-nav-block --no-drop-in-block --frames-per-launch 1 > $R/gpurun_out/q_${V}_a.log 2>&1
+timeout -k 10 150 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --no-nav-block --no-drop-in-block --frames-per-launch 1 > $R/gpurun_out/q_${V}_c.log 2>&1
+timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/q_${V}_b -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-fit --no-nav-block --no-drop-in-block --frames-per-launch 1 > $R/gpurun_out/q_${V}_b.log 2>&1
 python3 - <<PY
 import csv, glob, os, collections
 for tag in ("a", "b", "c"):
