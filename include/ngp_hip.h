@@ -445,6 +445,12 @@ int ngp_nav_density_forward(const ngp_nav_field_t* field_host, const void* prepa
  * activation.py:16-18; zero outside [-bound, bound]^3 like the encoder's dy_dx). */
 int ngp_nav_density_backward(const ngp_nav_field_t* field_host, const void* prepared, const float* xyz, uint32_t M, const float* grad_sigma,
                              const float* grad_geo, float* grad_xyz, void* stream);
+/* The planner's query in ONE launch (nav/quad_plot.py:224-250 over simulate.py:340-343): sigma [M] and jac [M,3] = d sigma / d xyz (trunc_exp's backward
+ * factor included: grad_xyz = grad_sigma * jac), a point's 16 levels split over the four waves of a workgroup -- built for a few thousand points, where
+ * the one-lane-per-point kernels above are latency-bound.  rot9_host: NULL, or a row-major 3x3 matrix applied as xyz @ rot before the field
+ * (simulate.py:340's axis change), its transpose applied to the Jacobian. */
+int ngp_nav_density_value_jac(const ngp_nav_field_t* field_host, const void* prepared, const float* xyz, uint32_t M, const float* rot9_host,
+                              float* sigma, float* jac, void* stream);
 
 /* NeRFRenderer.run (nerf/renderer.py:125-254) with upsample_steps = 0 and perturb = False, one workgroup per ray: nears, fars [N] from
  * ngp_near_far_from_aabb; aabb [6] and bg_color [3] on the host; image [N,3] (background mixed in), depth [N], weights_sum [N].

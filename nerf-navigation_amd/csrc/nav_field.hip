@@ -313,6 +313,134 @@ __global__ __launch_bounds__(NV_BLOCK) void k_nav_density_bwd(nav_params P, cons
 }
 
 // ---------------------------------------------------------------------------
+// The planner's query (nav/quad_plot.py:224-250 through simulate.py:340-343): sigma AND d sigma / d x for a FEW THOUSAND points, in one launch.
+//
+// k_nav_density_fwd / _bwd walk a point's 16 levels in one lane: for 10,000 body points that is 40 workgroups on 256 CUs, each waiting for 16 dependent
+// gather round trips and a 6,000-FMA matrix-vector chain on one wave -- slower than the level-parallel op chain (0.21 against 0.15 ms).  Here a
+// point's levels are split over the FOUR WAVES of its workgroup (64 points per workgroup, lane = point, wave w = levels 4w..4w+3): all 32 gathers of a
+// lane are issued before the first use (one round trip), each wave accumulates its share of the first layer, the shares meet in LDS, and since only
+// sigma = exp(out[0]) is asked for, the second layer is ONE row: out0 = W2[0] . relu(h) and d out0 / d h = W2[0] masked by the ReLU -- no matrix-vector
+// product on the way back.  The Jacobian reuses the corner values the forward gathered (nv_level_grad would fetch them again).
+// `rot`: simulate.py:340's axis change x @ rot folded in (a 3x3 row-major matrix or null): p = x rot on the way in, d sigma / d x = rot (d sigma / d p) on the
+// way out.  jac already contains trunc_exp's backward factor exp(clamp(out0, -15, 15)) (activation.py:16-18): grad_x = grad_sigma * jac.
+// ---------------------------------------------------------------------------
+struct nav_rot { float m[9]; uint32_t on; };
+static constexpr uint32_t NV_VJ_POINTS = 64;
+static constexpr size_t NV_VJ_LDS = sizeof(float) * (4 * NV_H * 64 + NV_H * 64 + 4 * 64 + 4 * 3 * 64);      // h shares | d out0 / d h | out0 shares | gradient shares
+
+__global__ __launch_bounds__(256) void k_nav_density_vj(nav_params P, nav_rot R, const float* __restrict__ xyz, uint32_t M, float* __restrict__ sigma,
+                                                        float* __restrict__ jac) {
+    extern __shared__ float nv_smem[];
+    float* lds_h = nv_smem;                                              // [4 waves][64 j][64 lanes]
+    float* lds_gh = lds_h + 4 * NV_H * 64;                               // [64 j][64 lanes]
+    float* lds_o = lds_gh + NV_H * 64;                                   // [4][64]
+    float* lds_a = lds_o + 4 * 64;                                       // [4][3][64]
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t i = blockIdx.x * NV_VJ_POINTS + lane;
+    const uint32_t ic = i < M ? i : M - 1;
+    const float wx = xyz[3ull * ic], wy = xyz[3ull * ic + 1], wz = xyz[3ull * ic + 2];
+    float px = wx, py = wy, pz = wz;
+    if (R.on) {                                                          // p = x @ rot (row vector times matrix)
+        px = (wx * R.m[0] + wy * R.m[3]) + wz * R.m[6];
+        py = (wx * R.m[1] + wy * R.m[4]) + wz * R.m[7];
+        pz = (wx * R.m[2] + wy * R.m[5]) + wz * R.m[8];
+    }
+    float x0, x1, x2;
+    const bool inside = nv_normalise(P, px, py, pz, x0, x1, x2);
+
+    // ---- this wave's four levels: cells, all 32 corner rows in flight at once ----
+    nv_cell c[4];
+    float2 v[4][8];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int l = (int)(4u * wave) + k;
+        c[k] = nv_locate(P.lv.scale[l], x0, x1, x2);
+        #pragma unroll
+        for (int q = 0; q < 8; q++) v[k][q] = P.table[nv_row(P, l, c[k].gx + (q & 1), c[k].gy + ((q >> 1) & 1), c[k].gz + (q >> 2))];
+    }
+    // ---- its share of the hidden pre-activations: h += W1t[2l] e0 + W1t[2l+1] e1 (nv_hidden's order inside a level) ----
+    {
+        float h[NV_H];
+        #pragma unroll
+        for (int j = 0; j < NV_H; j++) h[j] = 0.0f;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float e0 = 0.0f, e1 = 0.0f;
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float w = (((q & 1) ? c[k].fx : 1.0f - c[k].fx) * ((q & 2) ? c[k].fy : 1.0f - c[k].fy)) * ((q & 4) ? c[k].fz : 1.0f - c[k].fz);
+                e0 = __builtin_fmaf(w, v[k][q].x, e0);
+                e1 = __builtin_fmaf(w, v[k][q].y, e1);
+            }
+            if (!inside) { e0 = 0.0f; e1 = 0.0f; }
+            const nv_wptr wa = nv_hide(P.w1t) + (2 * (4 * wave + k)) * NV_H;
+            const nv_wptr wb = wa + NV_H;
+            #pragma unroll
+            for (int j = 0; j < NV_H; j++) h[j] = __builtin_fmaf(wa[j], e0, h[j]);
+            #pragma unroll
+            for (int j = 0; j < NV_H; j++) h[j] = __builtin_fmaf(wb[j], e1, h[j]);
+        }
+        #pragma unroll
+        for (int j = 0; j < NV_H; j++) lds_h[(wave * NV_H + j) * 64 + lane] = h[j];
+    }
+    __syncthreads();
+    // ---- wave w owns hidden units 16w .. 16w+15: sum the four shares (fixed order), ReLU, its part of out0 = W2[0] . relu(h) and of d out0 / d h ----
+    {
+        const nv_wptr w2 = nv_hide(P.w2);                                // row 0 of sigma_net.1.weight [16][64]
+        float o = 0.0f;
+        #pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = (int)(16u * wave) + jj;
+            const float hj = ((lds_h[(0 * NV_H + j) * 64 + lane] + lds_h[(1 * NV_H + j) * 64 + lane]) + lds_h[(2 * NV_H + j) * 64 + lane]) + lds_h[(3 * NV_H + j) * 64 + lane];
+            const float wj = w2[j];
+            o = __builtin_fmaf(wj, fmaxf(hj, 0.0f), o);
+            lds_gh[j * 64 + lane] = hj > 0.0f ? wj : 0.0f;
+        }
+        lds_o[wave * 64 + lane] = o;
+    }
+    __syncthreads();
+    const float out0 = ((lds_o[lane] + lds_o[64 + lane]) + lds_o[128 + lane]) + lds_o[192 + lane];
+    // ---- back through the first layer for this wave's levels, contracted with the trilinear Jacobian of the corners it still holds ----
+    {
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const nv_wptr wa = nv_hide(P.w1t) + (2 * (4 * wave + k)) * NV_H;
+            const nv_wptr wb = wa + NV_H;
+            float g0 = 0.0f, g1 = 0.0f;
+            #pragma unroll
+            for (int j = 0; j < NV_H; j++) { const float gj = lds_gh[j * 64 + lane]; g0 = __builtin_fmaf(wa[j], gj, g0); g1 = __builtin_fmaf(wb[j], gj, g1); }
+            float sv[8];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) sv[q] = __builtin_fmaf(g0, v[k][q].x, g1 * v[k][q].y);
+            const float fx = c[k].fx, fy = c[k].fy, fz = c[k].fz, wx0 = 1.0f - fx, wy0 = 1.0f - fy, wz0 = 1.0f - fz;
+            const float dx = (wy0 * wz0) * (sv[1] - sv[0]) + (fy * wz0) * (sv[3] - sv[2]) + (wy0 * fz) * (sv[5] - sv[4]) + (fy * fz) * (sv[7] - sv[6]);
+            const float dy = (wx0 * wz0) * (sv[2] - sv[0]) + (fx * wz0) * (sv[3] - sv[1]) + (wx0 * fz) * (sv[6] - sv[4]) + (fx * fz) * (sv[7] - sv[5]);
+            const float dz = (wx0 * wy0) * (sv[4] - sv[0]) + (fx * wy0) * (sv[5] - sv[1]) + (wx0 * fy) * (sv[6] - sv[2]) + (fx * fy) * (sv[7] - sv[3]);
+            const float scale = P.lv.scale[4 * wave + k];
+            ax = __builtin_fmaf(scale, dx, ax); ay = __builtin_fmaf(scale, dy, ay); az = __builtin_fmaf(scale, dz, az);
+        }
+        lds_a[(wave * 3 + 0) * 64 + lane] = ax; lds_a[(wave * 3 + 1) * 64 + lane] = ay; lds_a[(wave * 3 + 2) * 64 + lane] = az;
+    }
+    __syncthreads();
+    if (wave != 0 || i >= M) return;
+    float a[3];
+    #pragma unroll
+    for (int d = 0; d < 3; d++) a[d] = ((lds_a[(0 * 3 + d) * 64 + lane] + lds_a[(1 * 3 + d) * 64 + lane]) + lds_a[(2 * 3 + d) * 64 + lane]) + lds_a[(3 * 3 + d) * 64 + lane];
+    const float k = (inside ? P.r2b : 0.0f) * nv_exp_clamped(out0);      // d x01 / d p, times trunc_exp's backward factor
+    const float gpx = a[0] * k, gpy = a[1] * k, gpz = a[2] * k;
+    float gx = gpx, gy = gpy, gz = gpz;
+    if (R.on) {                                                          // d sigma / d x = rot . (d sigma / d p)
+        gx = (R.m[0] * gpx + R.m[1] * gpy) + R.m[2] * gpz;
+        gy = (R.m[3] * gpx + R.m[4] * gpy) + R.m[5] * gpz;
+        gz = (R.m[6] * gpx + R.m[7] * gpy) + R.m[8] * gpz;
+    }
+    sigma[i] = expf(out0);                                               // trunc_exp forward (activation.py:9-10)
+    jac[3ull * i] = gx; jac[3ull * i + 1] = gy; jac[3ull * i + 2] = gz;
+}
+
+// ---------------------------------------------------------------------------
 // NeRFRenderer.run (nerf/renderer.py:125-254) with upsample_steps = 0, perturb = False
 // ---------------------------------------------------------------------------
 
@@ -609,7 +737,8 @@ static int nav_allow_big_lds() {
     if (hipGetDevice(&device) != hipSuccess || device < 0) return ngp_fail(NGP_ELAUNCH, "nav: no current device");
     const unsigned long long bit = 1ull << (device & 63);
     if (device < 64 && (devices.load(std::memory_order_acquire) & bit)) return NGP_OK;
-    const void* kernels[4] = {(const void*)k_nav_density_fwd, (const void*)k_nav_density_bwd, (const void*)k_nav_run_fwd, (const void*)k_nav_run_bwd};
+    const void* kernels[5] = {(const void*)k_nav_density_fwd, (const void*)k_nav_density_bwd, (const void*)k_nav_run_fwd, (const void*)k_nav_run_bwd,
+                              (const void*)k_nav_density_vj};
     for (const void* k : kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return ngp_fail(NGP_ELAUNCH, "nav: cannot raise the dynamic LDS limit");
@@ -676,6 +805,22 @@ extern "C" int ngp_nav_density_backward(const ngp_nav_field_t* f, const void* pr
     { const int rc_lds = nav_allow_big_lds(); if (rc_lds != NGP_OK) return rc_lds; }
     hipLaunchKernelGGL(k_nav_density_bwd, dim3(ngp_div_up(M, NV_BLOCK)), dim3(NV_BLOCK), sizeof(float) * (16 + NV_H * NV_BLOCK), (hipStream_t)stream, P, xyz, M, grad_sigma, grad_geo, grad_xyz);
     NGP_CHECK_LAUNCH("nav_density_backward");
+    return NGP_OK;
+}
+
+extern "C" int ngp_nav_density_value_jac(const ngp_nav_field_t* f, const void* prepared, const float* xyz, uint32_t M, const float* rot9_host, float* sigma,
+                                         float* jac, void* stream) {
+    nav_params P;
+    const int rc = nav_fill("nav_density_value_jac", f, prepared, P);
+    if (rc != NGP_OK) return rc;
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyz && sigma && jac, "nav_density_value_jac: null pointer");
+    nav_rot R;
+    R.on = rot9_host ? 1u : 0u;
+    for (int k = 0; k < 9; k++) R.m[k] = rot9_host ? rot9_host[k] : (k % 4 == 0 ? 1.0f : 0.0f);
+    { const int rc_lds = nav_allow_big_lds(); if (rc_lds != NGP_OK) return rc_lds; }
+    hipLaunchKernelGGL(k_nav_density_vj, dim3(ngp_div_up(M, NV_VJ_POINTS)), dim3(256), NV_VJ_LDS, (hipStream_t)stream, P, R, xyz, M, sigma, jac);
+    NGP_CHECK_LAUNCH("nav_density_value_jac");
     return NGP_OK;
 }
 

@@ -250,6 +250,33 @@ class _nav_density(torch.autograd.Function):
         return gx, None
 
 
+class _nav_density_vj(torch.autograd.Function):
+    """sigma AND d sigma / d x for [M,3] points in ONE launch (ngp_nav_density_value_jac: a point's 16 levels over the four waves of a workgroup; the planner's
+    batch sizes), the axis change `x @ rot` of simulate.py:340 folded in.  backward = grad_sigma * jac, a constant of any second pass like the reference's
+    encoder backward."""
+
+    @staticmethod
+    def forward(ctx, x, owner, rot9):
+        import ctypes
+        import ngp_hip as _hip
+        x = x.contiguous().float()
+        M = x.shape[0]
+        sigma = torch.empty(M, dtype=torch.float32, device=x.device)
+        jac = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        st, prep = owner.struct()
+        rot = (ctypes.c_float * 9)(*rot9) if rot9 is not None else None
+        with torch.cuda.device(x.device):
+            _hip.check(_hip.lib().ngp_nav_density_value_jac(ctypes.byref(st), _hip.ptr(prep), _hip.ptr(x), M, rot, _hip.ptr(sigma), _hip.ptr(jac), _hip.stream()),
+                       "nav_density_value_jac")
+        ctx.save_for_backward(jac)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, grad_sigma):
+        (jac,) = ctx.saved_tensors
+        return (grad_sigma.detach().reshape(-1, 1) * jac).detach(), None, None
+
+
 class _nav_run(torch.autograd.Function):
     """NeRFRenderer.run(num_steps, upsample_steps = 0, perturb = False) for [N,3] rays: one launch forward, one backward to the rays.
     Second derivatives (the pose filter's Hessian, nav/estimator_helpers.py:384): in the reference every path from the rays to the image crosses an
@@ -315,16 +342,21 @@ class NativeNavQueries(NavQueries):
         self.native = _NativeField(self.renderer)
         self.num_steps, self.max_ray_batch = int(num_steps), int(max_ray_batch)
 
-    # One lane evaluates one point through all 16 levels, so a small batch (the planner's 10,000 body points = 40 workgroups) is bound by
-    # that lane's 16 dependent gather round trips: below this many points the level-parallel op chain (NavQueries.density_fn, 0.15 ms as
-    # one hipGraph replay) is the faster route; the A* occupancy query (10^6 points, nav/quad_plot.py:65-79) and the filter are far above it.
+    # The one-lane-per-point kernels walk a point's 16 levels serially: a small batch (the planner's 10,000 body points = 40 workgroups) is bound by that
+    # lane's 16 dependent gather round trips.  Below this many points the query is ONE launch of the level-parallel value-and-Jacobian kernel
+    # (ngp_nav_density_value_jac, the axis change folded in); the A* occupancy query (10^6 points, nav/quad_plot.py:65-79) and the filter are far above it.
     NATIVE_MIN_POINTS = 32768
+    _ROT9 = tuple(v for row in ROT for v in row)
 
     def density_fn(self, x):
         if x.numel() // 3 < self.NATIVE_MIN_POINTS:
-            return super().density_fn(x)
+            return _nav_density_vj.apply(x.reshape(-1, 3), self.native, self._ROT9).reshape(x.shape[:-1])
         pts = x.reshape(-1, 3) @ self._rot_on(x.device)
         return _nav_density.apply(pts, self.native).reshape(x.shape[:-1])
+
+    def density_fn_chain(self, x):
+        """the level-parallel op chain (NavQueries.density_fn) whatever the batch size (tests, timing)"""
+        return super().density_fn(x)
 
     def density_fn_native(self, x):
         """the fused kernels whatever the batch size (tests, timing)"""

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "ngp_nav_field_prepare": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "ngp_nav_density_forward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_nav_density_backward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp]),
+    "ngp_nav_density_value_jac": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp]),
     "ngp_nav_run_saved_bytes": (c_sz, [c_u32, c_u32]),
     "ngp_nav_run_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_nav_run_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),

@@ -42,15 +42,19 @@ def queries(dev):
     return {"chain": nav.NavQueries(ren, g["mf_intrinsics"], H, Wd, **kw), "native": nav.NativeNavQueries(ren, g["mf_intrinsics"], H, Wd, **kw)}
 
 
-def density_of(q, which):
-    return q.density_fn_native if which == "native" else q.density_fn
+def density_of(queries, which):
+    """chain: the level-parallel op chain over the drop-in encoder; native: the one-lane-per-point fused kernels (A*-sized batches); vj: what
+    NativeNavQueries.density_fn does with a planner-sized batch -- ONE launch of the value-and-Jacobian kernel, the axis change folded in"""
+    if which == "chain":
+        return queries["chain"].density_fn
+    return queries["native"].density_fn_native if which == "native" else queries["native"].density_fn
 
 
-@pytest.mark.parametrize("which", ["chain", "native"])
+@pytest.mark.parametrize("which", ["chain", "native", "vj"])
 @pytest.mark.parametrize("tag", ["pl", "plf"])
 def test_planner_cost_and_gradient(queries, dev, which, tag):
     g = NC.gold()
-    fn = density_of(queries[which], which)
+    fn = density_of(queries, which)
     with torch.no_grad():
         sigma = fn(torch.from_numpy(g[f"{tag}_points"]).to(dev)).cpu().numpy()
     assert np.max(np.abs(sigma - g[f"{tag}_sigma"]) / g[f"{tag}_sigma"]) < 2e-5

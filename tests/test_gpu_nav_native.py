@@ -66,6 +66,41 @@ def test_native_density_value_and_gradient(model, dev):
     assert torch.allclose(s1, s2, rtol=2e-5, atol=0) and rel(x.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-4
 
 
+def test_value_and_jacobian_query_against_oracle_and_the_one_lane_kernels(model, dev):
+    """ngp_nav_density_value_jac (the planner-sized query: one launch, 16 levels over four waves, `x @ rot` folded in): sigma 2e-5 relative and the gradient
+    1e-4 in norm / 1e-3 of the largest entry against the oracle (the tolerances of the other routes); points outside the box (zero gradient), a batch that
+    is not a multiple of 64, no rotation; and what NativeNavQueries.density_fn routes to it"""
+    from ngp import nav
+    q, orc = model["q"], model["oracle"]
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, size=(20, 500, 3)).astype(np.float32)
+    pts[0, :4] = [[2.5, 0, 0], [0, -2.2, 0.3], [1.999, 1.999, -1.999], [0, 0, 0]]
+    w = rng.uniform(0.5, 1.5, size=(20, 500)).astype(np.float32)
+    pg = t(pts, dev).requires_grad_(True)
+    sg = q.density_fn(pg)                                                    # 10,000 points < NATIVE_MIN_POINTS: the value-and-Jacobian kernel
+    assert sg.shape == (20, 500)
+    (sg * t(w, dev)).sum().backward()
+    po = torch.from_numpy(pts).requires_grad_(True)
+    so = orc.density(po.reshape(-1, 3) @ torch.tensor(nav.ROT))["sigma"].reshape(20, 500)
+    (so * torch.from_numpy(w)).sum().backward()
+    assert np.max(np.abs(sg.detach().cpu().numpy() - so.detach().numpy()) / so.detach().numpy()) < 2e-5
+    g, go = pg.grad.cpu().numpy(), po.grad.numpy()
+    assert rel(g, go) < 1e-4 and np.max(np.abs(g - go)) < 1e-3 * np.abs(go).max()
+    assert np.all(g[0, :2] == 0) and np.abs(g[0, 3]).sum() > 0
+    # against the one-lane kernels on the same points: same sums in another order
+    p2 = t(pts, dev).requires_grad_(True)
+    s2 = q.density_fn_native(p2)
+    (s2 * t(w, dev)).sum().backward()
+    assert torch.allclose(sg, s2, rtol=2e-6, atol=0) and rel(g, p2.grad.cpu().numpy()) < 2e-5
+    # 777 points, no rotation, through the op itself; no gradient requested
+    x = t(rng.uniform(-2, 2, size=(777, 3)).astype(np.float32), dev)
+    with torch.no_grad():
+        s3 = nav._nav_density_vj.apply(x, q.native, None)
+        s4 = nav._nav_density.apply(x, q.native)
+    assert torch.allclose(s3, s4, rtol=2e-6, atol=0)
+    assert nav._nav_density_vj.apply(x[:0], q.native, None).shape == (0,)
+
+
 @pytest.mark.parametrize("num_steps", [512, 100])
 def test_native_run_image_and_ray_gradients(model, dev, num_steps):
     """N2 (simulate.py:346): render_fn on 1,024 rays: image / depth 2e-4 abs, d L / d rays 2e-3 in norm against the oracle -- the
