@@ -215,17 +215,38 @@ __device__ __forceinline__ void ft_train_forward_loop(const rf_params& P, const 
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
     const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
     const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
+    // a pair's memory operands, fetched one pair ahead (pass 2 of the two-pass forward is two MFMA chains per pair behind three loads: without the
+    // prefetch every pair starts with an exposed ~2 us round trip)
+    struct fw_raw { float p[2][3], d[2][3]; ngp_h8 x[2]; };
+    auto fetch = [&](uint32_t pr) {
+        fw_raw r;
+        #pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const uint32_t mn = pr * 32 + 16 * n + s;
+            const uint64_t mm = mn < M ? mn : 0;
+            #pragma unroll
+            for (int k = 0; k < 3; k++) r.d[n][k] = dirs[3 * mm + k];
+            if (encoded) r.x[n] = ft_enc_load(enc, Mp, mn, g);     // pass 2: k_ft_encode_levels has filled the buffer (wave-uniform choice)
+            else {
+                #pragma unroll
+                for (int k = 0; k < 3; k++) r.p[n][k] = xyzs[3 * mm + k];
+            }
+        }
+        return r;
+    };
+    fw_raw cur;
+    if (wave < npairs) cur = fetch(wave);
     for (uint32_t pair = wave; pair < npairs; pair += nwaves) {
+        fw_raw nxt = cur;
+        if (pair + nwaves < npairs) nxt = fetch(pair + nwaves);
         ngp_h8 x[2];
         ngp_h4 shq[2];
         uint32_t m[2];
         #pragma unroll
         for (int n = 0; n < 2; n++) {
             m[n] = pair * 32 + 16 * n + s;
-            const uint64_t mm = m[n] < M ? m[n] : 0;
-            const float px = xyzs[3 * mm], py = xyzs[3 * mm + 1], pz = xyzs[3 * mm + 2];
             float sh[16];
-            sh_eval<4>(dirs[3 * mm], dirs[3 * mm + 1], dirs[3 * mm + 2], P.shn, sh);
+            sh_eval<4>(cur.d[n][0], cur.d[n][1], cur.d[n][2], P.shn, sh);
             #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = sh[j];
@@ -234,12 +255,13 @@ __device__ __forceinline__ void ft_train_forward_loop(const rf_params& P, const 
                 if (g == 3) v = sh[12 + j];
                 shq[n][j] = ngp_f2h(v);
             }
-            if (encoded) x[n] = ft_enc_load(enc, Mp, m[n], g);     // pass 2 of the two-pass forward: k_ft_encode_levels has filled the buffer (wave-uniform choice)
+            if (encoded) x[n] = cur.x[n];
             else {
-                x[n] = rf_encode<false>(P, lv, cls, px, py, pz);
+                x[n] = rf_encode<false>(P, lv, cls, cur.p[n][0], cur.p[n][1], cur.p[n][2]);
                 ft_enc_store(enc, Mp, m[n], g, x[n]);              // the buffer is padded to whole pairs of tiles
             }
         }
+        cur = nxt;
         float sg[2], cr[2], cg[2], cb[2];
         rv_mlp_tiles<2>(lds_w, lane, x, shq, sg, cr, cg, cb);
         #pragma unroll
@@ -394,8 +416,36 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
     for (int k = 0; k < NACC; k++) acc[k] = zero;
 
     const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
-    const uint32_t npairs = (M + 31) >> 5;
+    const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
+    // What a pair reads from memory, fetched ONE PAIR AHEAD: the kernel runs one wave per SIMD (400+ registers), so nothing else hides the ~2 us between a
+    // pair's first load and its first use -- 55 pairs per wave on an early 1.8 M-point batch.  The next pair's loads are issued before this pair's two
+    // MFMA chains and have landed when the loop comes round (22 / 12 registers).
+    struct ft_raw { ngp_h8 x[2]; float d[2][3], gs[2], gc[2][3]; ngp_h4 go[2]; };
+    auto fetch = [&](uint32_t pr) {
+        ft_raw r;
+        #pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const uint32_t mn = pr * 32 + 16 * n + s;
+            const uint64_t mm = mn < M ? mn : 0;
+            r.x[n] = ft_enc_load(enc, Mp, mn, g);
+            if constexpr (PART == 0) {
+                #pragma unroll
+                for (int k = 0; k < 3; k++) r.d[n][k] = dirs[3 * mm + k];
+                const bool own = g == 0 && mn < M;             // lanes of group 0 hold rows 0..3 of the output tiles
+                r.gs[n] = own ? grad_sigmas[mm] : 0.0f;
+                #pragma unroll
+                for (int k = 0; k < 3; k++) r.gc[n][k] = own ? grad_rgbs[3 * mm + k] : 0.0f;
+            } else {
+                r.go[n] = grad_outs[(size_t)(pr * 2 + n) * 64 + lane];
+            }
+        }
+        return r;
+    };
+    ft_raw cur;
+    if (wave < npairs) cur = fetch(wave);
     for (uint32_t pair = wave; pair < npairs; pair += nwaves) {
+        ft_raw nxt = cur;
+        if (pair + nwaves < npairs) nxt = fetch(pair + nwaves);       // (wave-uniform)
         ngp_h8 x[2];
         ngp_h4 shq[2];
         uint32_t m[2];
@@ -403,9 +453,8 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
         for (int n = 0; n < 2; n++) {
             m[n] = pair * 32 + 16 * n + s;
             if constexpr (PART == 0) {
-                const uint64_t mm = m[n] < M ? m[n] : 0;
                 float sh[16];
-                sh_eval<4>(dirs[3 * mm], dirs[3 * mm + 1], dirs[3 * mm + 2], P.shn, sh);
+                sh_eval<4>(cur.d[n][0], cur.d[n][1], cur.d[n][2], P.shn, sh);
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float v = sh[j];
@@ -415,7 +464,7 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
                     shq[n][j] = ngp_f2h(v);
                 }
             }
-            x[n] = ft_enc_load(enc, ((M + 31) >> 5) << 5, m[n], g);
+            x[n] = cur.x[n];
         }
         ft_acts A;
         ft_recompute<PART == 0>(lds_w, lane, x, shq, A);
@@ -435,11 +484,11 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
                     for (int k = 0; k < 3; k++) {
                         // torch.sigmoid on the half logits, its backward on halves: half(float(half(grad)) * (1 - s) * s)   (opmath float)
                         const float sv = rf_h(1.0f / (1.0f + ngp_expf(-rf_h(A.ho[n][k]))));
-                        const float gh = rf_h(grad_rgbs[3ull * m[n] + k]);
+                        const float gh = rf_h(cur.gc[n][k]);
                         gout[n][k] = ngp_f2h((gh * (1.0f - sv)) * sv);
                     }
                     // trunc_exp backward (activation.py:17-21): g * exp(clamp(x, max = 15)), float32, then autograd's cast to the half input
-                    sig_grad[n] = rf_h(grad_sigmas[m[n]] * ngp_expf(fminf(rf_h(A.hs[n][0]), 15.0f)));
+                    sig_grad[n] = rf_h(cur.gs[n] * ngp_expf(fminf(rf_h(A.hs[n][0]), 15.0f)));
                 }
             }
             {   // step 1: c3 <- colour logits; dV_out = g_out^T c3
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
             ngp_h8 gsig[2];
             #pragma unroll
             for (int n = 0; n < 2; n++) {
-                const ngp_h4 go = grad_outs[(size_t)(pair * 2 + n) * 64 + lane];
+                const ngp_h4 go = cur.go[n];
                 gsig[n] = hzero;
                 #pragma unroll
                 for (int r = 0; r < 4; r++) gsig[n][r] = go[r];
@@ -552,6 +601,7 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
                 }
             }
         }
+        cur = nxt;
     }
 
     // ---- the workgroup's weight gradients: sum the four waves through LDS (fixed order), then this workgroup's row of the partial-sum buffer: plain
