@@ -264,7 +264,7 @@ def fit_model(args, dev, W, teacher):
         train = {"what": f"the last {tail} of the {args.fit_steps} fit steps (4,096 rays per step, FFMLP field under autocast, native Adam + GradScaler, grid refresh every 16 steps: "
                          "BASELINE config 3, steady state)", "steps": tail, "ms_per_step": 1e3 * wall / tail, "rays_per_s": n_rays * tail / wall,
                  "points_per_step": points, "host_queue_ms_per_step": 1e3 * queued / tail,
-                 "forward_roofline": roof("k_field_train_forward (gather 512 B per point + both networks)", timers["field_train_forward"]),
+                 "forward_roofline": roof("k_ft_encode_levels + k_field_train_forward (level-by-level gather of 512 B per point, then both networks), event-timed together", timers["field_train_forward"]),
                  "scatter_roofline": roof("k_gs_bin + k_gs_accumulate (binned table-gradient scatter)", timers["grid_encode_backward"]),
                  "field_backward_ms": timers["field_train_backward"], "optimizer_ms": timers["adam_step"]}
     torch.cuda.synchronize()

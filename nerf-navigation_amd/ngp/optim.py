@@ -22,7 +22,13 @@ class NativeAdam(torch.optim.Optimizer):
         loss = opt.scale_loss(loss); loss.backward(); opt.step()          # = scaler.scale(loss).backward(); scaler.step(opt); scaler.update()
 
     `param_groups` / `state` / `state_dict()` have torch.optim.Adam's layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), so LR schedulers and the
-    reference's checkpoints (nerf/utils.py:950-957, :1040-1060) work unchanged; `scaler_state_dict()` has GradScaler.state_dict()'s."""
+    reference's checkpoints (nerf/utils.py:950-957, :1040-1060) work unchanged; `scaler_state_dict()` has GradScaler.state_dict()'s.
+
+    Two restrictions against torch's class (`NGPTrainer` falls back to torch.optim.Adam + GradScaler where they would bite):
+      * at most `ngp_hip.ADAM_MAX_TENSORS` (16) parameter tensors per optimiser (one launch takes them all; the reference's fields have 3 or 6);
+      * ONE step count for all parameters: every parameter is updated in every unskipped step, as in the reference's training loop, where every
+        parameter receives a gradient in every step.  torch keeps a count per parameter, so a parameter that receives its first gradient later would get another
+        bias correction there; `load_state_dict` refuses a state whose per-parameter counts differ."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, scaler_enabled=True, init_scale=2.0 ** 16, growth_factor=2.0,
                  backoff_factor=0.5, growth_interval=2000):
