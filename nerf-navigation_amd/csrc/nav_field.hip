@@ -23,6 +23,9 @@
 #include <atomic>
 #include "ngp_sh.h"
 
+#ifndef NV_RUN_U
+#define NV_RUN_U 1                         // levels of the hash grid the run kernels may overlap (gathers in flight per lane: 8 x U); A/B: profiles/HISTORY.md 4.5
+#endif
 static constexpr int NV_L = 16;            // levels
 static constexpr int NV_H = 64;            // hidden width
 static constexpr int NV_GEO = 15;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(NV_BLOCK) void k_nav_run_fwd(nav_params P, nav_run 
         float x0, x1, x2;
         const bool inside = nv_normalise(P, s.px, s.py, s.pz, x0, x1, x2);
         float out[16];
-        const uint64_t relu = nv_density_forward(P, inside, x0, x1, x2, col, out);
+        const uint64_t relu = nv_density_forward<NV_RUN_U>(P, inside, x0, x1, x2, col, out);
         float alpha, keep;
         nv_alpha(s.znext_minus_z, P.density_scale, expf(out[0]), alpha, keep);
         if (!live) { alpha = 0.0f; keep = 1.0f; }
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(NV_BLOCK) void k_nav_run_bwd(nav_params P, nav_run 
         float x0, x1, x2;
         const bool inside = nv_normalise(P, s.px, s.py, s.pz, x0, x1, x2);
         float gx, gy, gz;
-        nv_density_backward(P, inside, x0, x1, x2, relu, gout, col, gx, gy, gz);
+        nv_density_backward<NV_RUN_U>(P, inside, x0, x1, x2, relu, gout, col, gx, gy, gz);
         if (!live) { gx = 0.0f; gy = 0.0f; gz = 0.0f; }
         gx *= s.bx; gy *= s.by; gz *= s.bz;                              // clipped coordinates pass no (or half the) gradient (:159)
         go0 += gx; go1 += gy; go2 += gz;

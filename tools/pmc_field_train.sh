@@ -24,7 +24,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$R/gpurun_out/ft_pmc*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for name in ("k_field_train_forward", "k_field_train_backward<0", "k_field_train_backward<1", "k_gs_bin", "k_gs_accumulate", "k_grid_forward"):
+        for name in ("k_ft_encode_levels", "k_field_train_forward", "k_field_train_backward<0", "k_field_train_backward<1", "k_gs_bin", "k_gs_accumulate", "k_grid_forward"):
             if name in k:
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in sorted(acc.items()):
