@@ -147,64 +147,71 @@ __device__ __forceinline__ void ft_enc_store(uint32_t* __restrict__ enc, uint32_
 // level's table -- 2 MB for a hashed level -- at a time, which an XCD's 4 MB L2 holds; the one-pass kernel has all 16 levels' 25 MB live at once and
 // ran at an L2 hit rate of 0.46 on ray-ordered points, 950 B per point past L2: profiles/r15_gather_rate.md).  One lane per sample.
 // Arithmetic per (sample, level): rf_encode's = k_grid_forward<half,3,2>'s (gridencoder.hip), operation for operation -- the same bits.
+#ifndef FT_ENC_SPT
+#define FT_ENC_SPT 2                       // samples per lane of k_ft_encode_levels (their 2 x 8 gathers are in flight together); A/B: profiles/HISTORY.md 4.3
+#endif
 __global__ __launch_bounds__(256) void k_ft_encode_levels(rf_params P, const float* __restrict__ xyzs, uint32_t M, uint32_t Mp, uint32_t* __restrict__ enc) {
-    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= Mp) return;
+    constexpr int SPT = FT_ENC_SPT;
     const uint32_t level = blockIdx.y;
-    uint32_t out = 0u;                                                     // padding samples and samples outside the box encode to zeros
-    if (m < M) {
+    // the level's constants (wave-uniform): get_grid_index (gridencoder.cu:54-72) -- strides grow while they fit; a level whose last stride does not fit is hashed
+    const uint32_t o0 = (uint32_t)P.offsets[level], size = (uint32_t)P.offsets[level + 1] - o0;
+    const float scale = P.scale[level];
+    const uint32_t side = P.resolution[level] + 1u;
+    uint32_t stride = 1, s1 = 0, s2 = 0;
+    #pragma unroll
+    for (int d = 0; d < 3; d++)
+        if (stride <= size) { if (d == 1) s1 = stride; if (d == 2) s2 = stride; stride *= side; }
+    const bool dense = stride <= size;
+    const bool pow2 = (size & (size - 1u)) == 0u;
+    const uint32_t* tab = P.table + o0;
+
+    uint32_t m[SPT], raw[SPT][8];
+    float f[SPT][3];
+    bool live[SPT];                                                        // a real sample inside the box (anything else encodes to zeros and gathers at the origin)
+    #pragma unroll
+    for (int q = 0; q < SPT; q++) {
+        m[q] = (blockIdx.x * SPT + q) * 256 + threadIdx.x;
+        const uint64_t mm = m[q] < M ? m[q] : 0;
         float x[3];
-        rf_normalise(P, xyzs[3ull * m], xyzs[3ull * m + 1], xyzs[3ull * m + 2], x[0], x[1], x[2]);
+        rf_normalise(P, xyzs[3 * mm], xyzs[3 * mm + 1], xyzs[3 * mm + 2], x[0], x[1], x[2]);
         const bool oob = (x[0] < 0 || x[0] > 1) || (x[1] < 0 || x[1] > 1) || (x[2] < 0 || x[2] > 1);
-        if (!oob) {
-            const uint32_t o0 = (uint32_t)P.offsets[level], size = (uint32_t)P.offsets[level + 1] - o0;
-            const float scale = P.scale[level];
-            const uint32_t side = P.resolution[level] + 1u;
-            // get_grid_index (gridencoder.cu:54-72): strides grow while they fit; a level whose last stride does not fit is hashed
-            uint32_t stride = 1, s1 = 0, s2 = 0;
+        live[q] = m[q] < M && !oob;
+        uint32_t pg[3];
+        #pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float p = (live[q] ? x[d] : 0.0f) * scale + 0.5f;
+            const float fl = floorf(p);
+            pg[d] = (uint32_t)fl;
+            f[q][d] = p - fl;
+        }
+        if (dense) {                                                       // x + y s1 + z s2 < size by construction
+            const uint32_t i0 = pg[0] + pg[1] * s1 + pg[2] * s2;
             #pragma unroll
-            for (int d = 0; d < 3; d++)
-                if (stride <= size) { if (d == 1) s1 = stride; if (d == 2) s2 = stride; stride *= side; }
-            const bool dense = stride <= size;
-            const bool pow2 = (size & (size - 1u)) == 0u;
-            float f[3];
-            uint32_t pg[3];
-            #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const float p = x[d] * scale + 0.5f;
-                const float fl = floorf(p);
-                pg[d] = (uint32_t)fl;
-                f[d] = p - fl;
-            }
-            const uint32_t* tab = P.table + o0;
-            uint32_t raw[8];
-            if (dense) {                                                   // x + y s1 + z s2 < size by construction
-                const uint32_t i0 = pg[0] + pg[1] * s1 + pg[2] * s2;
-                #pragma unroll
-                for (int c = 0; c < 8; c++) raw[c] = tab[i0 + (c & 1) + ((c & 2) ? s1 : 0u) + ((c & 4) ? s2 : 0u)];
-            } else {
-                constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;      // fast_hash (gridencoder.cu:35-51)
-                const uint32_t hy[2] = {pg[1] * P1, (pg[1] + 1u) * P1}, hz[2] = {pg[2] * P2, (pg[2] + 1u) * P2};
-                #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const uint32_t h = (pg[0] + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[c >> 2];
-                    raw[c] = tab[pow2 ? (h & (size - 1u)) : (h % size)];
-                }
-            }
-            // w = (wx * wy) * wz; acc = half(float(acc) + float(half(w * float(v)))) in the reference's corner order (gridencoder.cu:147-166)
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            h2 acc = {(_Float16)0.0f, (_Float16)0.0f};
+            for (int c = 0; c < 8; c++) raw[q][c] = tab[i0 + (c & 1) + ((c & 2) ? s1 : 0u) + ((c & 4) ? s2 : 0u)];
+        } else {
+            constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;          // fast_hash (gridencoder.cu:35-51)
+            const uint32_t hy[2] = {pg[1] * P1, (pg[1] + 1u) * P1}, hz[2] = {pg[2] * P2, (pg[2] + 1u) * P2};
             #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const float w = (((c & 1) ? f[0] : 1 - f[0]) * ((c & 2) ? f[1] : 1 - f[1])) * ((c & 4) ? f[2] : 1 - f[2]);
-                const h2 v = __builtin_bit_cast(h2, raw[c]);
-                const h2 prod = {ngp_f2h(w * (float)v.x), ngp_f2h(w * (float)v.y)};
-                acc = acc + prod;
+                const uint32_t h = (pg[0] + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[c >> 2];
+                raw[q][c] = tab[pow2 ? (h & (size - 1u)) : (h % size)];
             }
-            out = __builtin_bit_cast(uint32_t, acc);
         }
     }
-    enc[(size_t)level * Mp + m] = out;
+    // w = (wx * wy) * wz; acc = half(float(acc) + float(half(w * float(v)))) in the reference's corner order (gridencoder.cu:147-166)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    #pragma unroll
+    for (int q = 0; q < SPT; q++) {
+        h2 acc = {(_Float16)0.0f, (_Float16)0.0f};
+        #pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float w = (((c & 1) ? f[q][0] : 1 - f[q][0]) * ((c & 2) ? f[q][1] : 1 - f[q][1])) * ((c & 4) ? f[q][2] : 1 - f[q][2]);
+            const h2 v = __builtin_bit_cast(h2, raw[q][c]);
+            const h2 prod = {ngp_f2h(w * (float)v.x), ngp_f2h(w * (float)v.y)};
+            acc = acc + prod;
+        }
+        if (m[q] < Mp) enc[(size_t)level * Mp + m[q]] = live[q] ? __builtin_bit_cast(uint32_t, acc) : 0u;
+    }
 }
 
 template <bool FIXED>
@@ -693,7 +700,7 @@ extern "C" int ngp_field_train_forward(const ngp_field_t* field_host, const floa
     if (blocks > 256 * FT_FWD_WG_PER_CU) blocks = 256 * FT_FWD_WG_PER_CU;
     const bool two_pass = ft_two_pass.load(std::memory_order_relaxed) != 0 && M >= FT_TWO_PASS_MIN;
     if (two_pass) {
-        hipLaunchKernelGGL(k_ft_encode_levels, dim3(ngp_div_up(Mp, 256u), RF_L), dim3(256), 0, (hipStream_t)stream, P, xyzs, M, Mp, (uint32_t*)saved);
+        hipLaunchKernelGGL(k_ft_encode_levels, dim3(ngp_div_up(Mp, 256u * FT_ENC_SPT), RF_L), dim3(256), 0, (hipStream_t)stream, P, xyzs, M, Mp, (uint32_t*)saved);
         NGP_CHECK_LAUNCH("field_train_forward (encode)");
     }
     hipLaunchKernelGGL(k_field_train_forward, dim3(blocks), dim3(RF_BLOCK), 36 * 1024, (hipStream_t)stream, P, xyzs, dirs, M, sigmas, rgbs, (uint32_t*)saved, two_pass);

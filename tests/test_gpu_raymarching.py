@@ -365,3 +365,18 @@ def test_march_rays_many_slots_on_sparse_grids_bit_exact(oracle, dev, bound, cas
     assert_same_bits(l, l_ref, "deltas")
     assert_same_bits(x, x_ref, "xyzs")
     assert_same_bits(dd, d_ref, "dirs")
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 70000, 640001])
+def test_compact_alive_is_the_stable_mask_at_every_size(dev, n):
+    """`rays_alive[rays_alive >= 0]` (nerf/renderer.py:365) as two launches (count, then a write pass whose workgroups add up the counts before them): the same
+    elements in the same order and the count, for sizes around the workgroup width, a whole 800 x 800 frame, every-ray-dead, every-ray-alive and sparse survivors"""
+    import raymarching
+    g = torch.Generator(device="cpu").manual_seed(n)
+    for keep in (0.0, 1.0, 0.5, 0.01):
+        alive = torch.arange(n, dtype=torch.int32)
+        alive[torch.rand(n, generator=g) >= keep] = -1
+        packed, cnt = raymarching.compact_alive(alive.to(dev), n)
+        want = alive[alive >= 0]
+        assert int(cnt.item()) == want.numel()
+        assert torch.equal(packed[: want.numel()].cpu(), want)
