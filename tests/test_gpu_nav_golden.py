@@ -118,3 +118,34 @@ def test_hip_compositor_on_the_executed_run_operands(dev):
     composite_check(c, ws.cpu().numpy(), image.cpu().numpy())
     ws_o, depth_o, image_o = O.composite_rays_train_forward(sigmas, rgbs, deltas, rays)
     assert np.array_equal(ws.cpu().numpy(), ws_o) and np.array_equal(image.cpu().numpy(), image_o) and np.array_equal(depth.cpu().numpy(), depth_o)
+
+
+def test_hip_inference_compositor_iterated_on_the_executed_run_operands(dev):
+    """k_composite_rays + compact_alive driven like nerf/renderer.py:343-369 over what the executed run() computed: the image within the tolerances of
+    tests/test_nav_golden.py, and bit-equal to the oracle's compositor driven the same way"""
+    import raymarching
+    from oracle import ngp_oracle as O
+    from test_nav_golden import composite_check, iterate_composite_rays
+    c = np.load(os.path.join(NC.GOLD, "callers_composite.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)             # noqa: E731
+
+    def hip_composite(n_alive, n_step, alive, st, sig, rgb, deltas):
+        dev_state = {k: t(v) for k, v in st.items()}
+        a = t(alive)
+        raymarching.composite_rays(n_alive, n_step, a, dev_state["rays_t"], t(sig), t(rgb), t(deltas), dev_state["ws"], dev_state["depth"], dev_state["image"])
+        for k in st:
+            st[k][...] = dev_state[k].cpu().numpy()
+        return a
+
+    def hip_compact(a):
+        packed, cnt = raymarching.compact_alive(a, a.shape[0])
+        return packed[: int(cnt.item())].cpu().numpy()
+
+    def cpu_composite(n_alive, n_step, alive, st, sig, rgb, deltas):
+        alive = alive.copy()
+        O.composite_rays(n_alive, n_step, alive, st["rays_t"], sig, rgb, deltas, st["ws"], st["depth"], st["image"])
+        return alive
+    ws, image = iterate_composite_rays(c, hip_composite, hip_compact)
+    composite_check(c, ws, image)
+    ws_o, image_o = iterate_composite_rays(c, cpu_composite, lambda a: a[a >= 0])
+    assert np.array_equal(ws, ws_o) and np.array_equal(image, image_o)

@@ -149,3 +149,37 @@ def test_oracle_compositor_on_the_executed_run_operands():
     sigmas, rgbs, deltas, rays = composite_inputs(c)
     ws, depth, image = O.composite_rays_train_forward(sigmas, rgbs, deltas, rays)
     composite_check(c, ws, image)
+
+
+def iterate_composite_rays(c, composite, compact, n_step=8):
+    """The inference compositor driven like nerf/renderer.py:343-369 over run()'s operands: n_step samples of every alive ray per call, dead rays (-1)
+    compacted away between calls.  `composite(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, ws, depth, image)` mutates its arguments like the op;
+    `compact(rays_alive) -> kept`.  Returns (weights_sum, image) as numpy."""
+    N, T = c["exponent"].shape
+    sig_all, rgb_all = (-c["exponent"]).astype(np.float32), c["rgbs"].astype(np.float32)
+    ws, depth, image = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    rays_t = np.zeros(N, np.float32)
+    alive = np.arange(N, dtype=np.int32)
+    state = dict(ws=ws, depth=depth, image=image, rays_t=rays_t)
+    for k0 in range(0, T, n_step):
+        n_alive = alive.shape[0]
+        if n_alive == 0:
+            break
+        sig = np.ascontiguousarray(sig_all[alive, k0:k0 + n_step]).reshape(-1)
+        rgb = np.ascontiguousarray(rgb_all[alive, k0:k0 + n_step]).reshape(-1, 3)
+        deltas = np.ones((n_alive * n_step, 2), np.float32)                      # delta := 1: sigma * delta = -exponent; t counts samples
+        alive = compact(composite(n_alive, n_step, alive, state, sig, rgb, deltas))
+    return state["ws"], state["image"]
+
+
+def test_oracle_inference_compositor_iterated_on_the_executed_run_operands():
+    """SURVEY 8c relation 1, third formulation: iterated `composite_rays` (raymarching.cu:829-913: T = 1 - weights_sum, the T < 1e-4 test in double AFTER the
+    sample is accumulated, dead rays marked -1) on the operands of the executed run()"""
+    c = np.load(os.path.join(NC.GOLD, "callers_composite.npz"))
+
+    def composite(n_alive, n_step, alive, st, sig, rgb, deltas):
+        alive = alive.copy()
+        O.composite_rays(n_alive, n_step, alive, st["rays_t"], sig, rgb, deltas, st["ws"], st["depth"], st["image"])
+        return alive
+    ws, image = iterate_composite_rays(c, composite, lambda a: a[a >= 0])
+    composite_check(c, ws, image)
