@@ -380,6 +380,11 @@ int ngp_field_forward_half(const ngp_field_t* field_host, const float* xyzs, con
  *   field_host must describe the same half copies the forward used.  workspace: ngp_field_train_workspace(M) bytes, contents arbitrary
  *   (per-workgroup partial sums of the weight gradients, added in a fixed order: the gradients are bitwise reproducible; nothing to clear,
  *   ngp_field_train_workspace(0) == 0). */
+/* Density only (sigma = exp(h0) * field.density_scale) for M points in two launches: the level-by-level encoder of the training forward, then the
+ * density net on the matrix cores -- what the occupancy-grid refresh asks of the field (nerf/renderer.py:478-486,511-517 `self.density(xyzs)['sigma']`
+ * on millions of random cell positions).  Same logits as ngp_field_forward.  workspace: ngp_field_density_workspace(M) bytes. */
+size_t ngp_field_density_workspace(uint32_t M);
+int ngp_field_density(const ngp_field_t* field_host, const float* xyzs, uint32_t M, float* sigmas, void* workspace, size_t workspace_bytes, void* stream);
 size_t ngp_field_train_saved_bytes(uint32_t M);
 /* forward in two passes (default: the encoder level by level, one level's table live in L2 at a time, then the networks) or in one launch;
  * same values and the same `saved` layout either way; returns the previous setting (process-wide: A/B timing, tests). */

@@ -680,6 +680,92 @@ static uint32_t ft_bwd_blocks(uint32_t M) {
 static size_t ft_ws_outs_offset(uint32_t M) { return ((size_t)ft_bwd_blocks(M) * FT_WS_FLOATS * sizeof(float) + 255) & ~(size_t)255; }
 extern "C" size_t ngp_field_train_workspace(uint32_t M) { return ft_ws_outs_offset(M) + (size_t)((M + 31) >> 5) * 2 * 64 * sizeof(ngp_h4); }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Density only, for a few million INCOHERENT points: the occupancy-grid refresh (nerf/renderer.py:446-531 queries `density(xyzs)['sigma']` on
+// H^3 / 2 ... H^3 random cell positions per cascade every 16 training steps).  The same two passes as the training forward: k_ft_encode_levels
+// (level by level: random points are the case it was built for), then the density net alone on 16-sample tiles -- 14 MFMAs per tile instead of the
+// op chain's encoder + permute copy + FFMLP launch + exp (1.1 ms per 2.1 M points).  The logits are the one-launch field's (k_field_forward_lds) bit
+// for bit; sigma = exp(h0) through ngp_expf like there.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RF_BLOCK, 4) void k_field_density_mlp(rf_params P, const uint32_t* __restrict__ enc, uint32_t M, float* __restrict__ sigmas) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
+    ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rf_smem);                   // the density net's 14 fragments (the first 14 of rv_stage_weights' order)
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave_in_wg = threadIdx.x >> 6;
+    for (int f = wave_in_wg; f < 14; f += (int)(RF_BLOCK / 64)) {
+        ngp_h8 a;
+        if (f < 4) a = rf_load_a_sigma_in(P.w_sigma, f, lane);
+        else if (f < 12) a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32, MLP_W, (f - 4) >> 1, (f - 4) & 1, lane);
+        else a = mlp_load_a_permuted(P.w_sigma + MLP_W * 32 + MLP_W * MLP_W, MLP_W, 0, f - 12, lane);
+        lds_w[f * 64 + lane] = a;
+    }
+    __syncthreads();
+    const ngp_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
+    const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
+    ngp_h8 cur[2], nxt[2];
+    if (wave < npairs) { cur[0] = ft_enc_load(enc, Mp, wave * 32 + s, g); cur[1] = ft_enc_load(enc, Mp, wave * 32 + 16 + s, g); }
+    for (uint32_t pair = wave; pair < npairs; pair += nwaves) {
+        nxt[0] = cur[0]; nxt[1] = cur[1];
+        if (pair + nwaves < npairs) {                                     // the next pair's features, one pair ahead
+            nxt[0] = ft_enc_load(enc, Mp, (pair + nwaves) * 32 + s, g);
+            nxt[1] = ft_enc_load(enc, Mp, (pair + nwaves) * 32 + 16 + s, g);
+        }
+        ngp_h8 act[2][2];
+        {
+            ngp_f4 d[2][MLP_MT];
+            #pragma unroll
+            for (int t = 0; t < MLP_MT; t++) {
+                const ngp_h8 w = rv_frag(lds_w, t, lane);
+                #pragma unroll
+                for (int n = 0; n < 2; n++) d[n][t] = ngp_mfma(w, cur[n], zero);
+            }
+            #pragma unroll
+            for (int n = 0; n < 2; n++) { act[n][0] = mlp_pack_relu(d[n][0], d[n][1]); act[n][1] = mlp_pack_relu(d[n][2], d[n][3]); }
+        }
+        {
+            ngp_f4 d[2][MLP_MT];
+            #pragma unroll
+            for (int t = 0; t < MLP_MT; t++) {
+                const ngp_h8 w0 = rv_frag(lds_w, 4 + 2 * t, lane), w1 = rv_frag(lds_w, 5 + 2 * t, lane);
+                #pragma unroll
+                for (int n = 0; n < 2; n++) d[n][t] = ngp_mfma(w0, act[n][0], zero);
+                #pragma unroll
+                for (int n = 0; n < 2; n++) d[n][t] = ngp_mfma(w1, act[n][1], d[n][t]);
+            }
+            #pragma unroll
+            for (int n = 0; n < 2; n++) { act[n][0] = mlp_pack_relu(d[n][0], d[n][1]); act[n][1] = mlp_pack_relu(d[n][2], d[n][3]); }
+        }
+        const ngp_h8 w0 = rv_frag(lds_w, 12, lane), w1 = rv_frag(lds_w, 13, lane);
+        #pragma unroll
+        for (int n = 0; n < 2; n++) {
+            ngp_f4 h = ngp_mfma(w0, act[n][0], zero);
+            h = ngp_mfma(w1, act[n][1], h);
+            const uint32_t m = pair * 32 + 16 * n + s;
+            if (g == 0 && m < M) sigmas[m] = P.density_scale * ngp_expf(rf_h(h[0]));     // rv_activate's density line
+        }
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+    }
+}
+
+extern "C" size_t ngp_field_density_workspace(uint32_t M) { return (size_t)RF_L * (((size_t)(M + 31) >> 5) << 5) * sizeof(uint32_t); }
+
+extern "C" int ngp_field_density(const ngp_field_t* field_host, const float* xyzs, uint32_t M, float* sigmas, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    rf_params P;
+    int rc = rf_fill_params("field_density", field_host, P);
+    if (rc != NGP_OK) return rc;
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && sigmas && workspace, "field_density: null pointer");
+    NGP_REQUIRE(workspace_bytes >= ngp_field_density_workspace(M), "field_density: workspace too small (ngp_field_density_workspace)");
+    const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
+    hipLaunchKernelGGL(k_ft_encode_levels, dim3(ngp_div_up(Mp, 256u * FT_ENC_SPT), RF_L), dim3(256), 0, (hipStream_t)stream, P, xyzs, M, Mp, (uint32_t*)workspace);
+    uint32_t blocks = ngp_div_up(npairs, RF_BLOCK / 64);
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    hipLaunchKernelGGL(k_field_density_mlp, dim3(blocks), dim3(RF_BLOCK), 14 * 1024, (hipStream_t)stream, P, (const uint32_t*)workspace, M, sigmas);
+    NGP_CHECK_LAUNCH("field_density");
+    return NGP_OK;
+}
+
 // The forward in two passes (k_ft_encode_levels, then the networks) or in one (the gather fused with the networks); same values, same kept buffer.
 // Process-wide switch for A/B timing and tests; batches below FT_TWO_PASS_MIN points are latency-bound either way and take the single launch.
 static std::atomic<int> ft_two_pass{1};

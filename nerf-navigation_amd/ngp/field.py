@@ -234,6 +234,23 @@ class NGPFieldFF(_ParamEpoch, nn.Module):
         h = self.sigma_net(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
+    @torch.no_grad()
+    def density_sigma(self, x):
+        """`density(x)['sigma']` for a caller that wants nothing else and no gradient -- the occupancy-grid refresh (nerf/renderer.py:478-486,511-517), millions
+        of random points every 16 training steps.  Default field under autocast: two native launches (ngp_field_density: the level-by-level encoder of
+        the training forward + the density net on the matrix cores; the logits of `forward_fused` bit for bit) instead of encoder + permute + FFMLP + exp;
+        anything else: the op chain."""
+        if not (x.is_cuda and torch.is_autocast_enabled() and x.dim() == 2 and self.encoder.embeddings.dtype == torch.float32 and self._fused_shape_ok()):
+            return self.density(x)["sigma"].reshape(-1).float()
+        x = x.contiguous().float()
+        M = x.shape[0]
+        L = _hip.lib()
+        sig = torch.empty(M, dtype=torch.float32, device=x.device)
+        ws = _hip.workspace(L.ngp_field_density_workspace(M), x.device)
+        f = self.fused_state(1.0)
+        _hip.check(L.ngp_field_density(ctypes.byref(f), _hip.ptr(x), M, _hip.ptr(sig), _hip.ptr(ws), ws.numel(), _hip.stream()), "field_density")
+        return sig
+
     @staticmethod
     def _color_input(d, geo_feat):
         """cat(SH16, geo15, one zero column) (network_ff.py:67-68).  The SH features are float32 and geo_feat is half under autocast: the

@@ -446,10 +446,11 @@ class NGPRenderer(nn.Module):
                                                  _hip.ptr(xyzs), _hip.ptr(cells), _hip.ptr(ws), ws.numel(), _hip.stream()), "density_grid_sample")
             sigmas = torch.empty(n, dtype=torch.float32, device=dev)
             chunk = max(int(S), 1) ** 3
+            fused = getattr(self.field, "density_sigma", None)      # NGPFieldFF: two native launches where they apply (ngp/field.py), else its own op chain
             for head in range(0, n, chunk):
                 tail = min(head + chunk, n)
                 with _grid.level_major_forward():          # random points: one level's table at a time stays in L2 (gridencoder/grid.py)
-                    sigmas[head:tail] = self.density(xyzs[head:tail])["sigma"].reshape(-1).detach().float()
+                    sigmas[head:tail] = fused(xyzs[head:tail]) if fused is not None else self.density(xyzs[head:tail])["sigma"].reshape(-1).detach().float()
             mean = torch.empty(1, dtype=torch.float32, device=dev)
             _hip.check(L.ngp_density_grid_update(_hip.ptr(sigmas), _hip.ptr(cells), n, float(self.density_scale), float(decay),
                                                  float(self.density_thresh), cas, H, _hip.ptr(grid), _hip.ptr(self.density_bitfield),

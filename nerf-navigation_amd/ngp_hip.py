@@ -80,6 +80,8 @@ _SIGNATURES = {
     "ngp_free_splitk": (c_int, []),
     "ngp_field_forward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_field_forward_half": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp]),
+    "ngp_field_density_workspace": (c_sz, [c_u32]),
+    "ngp_field_density": (c_int, [c_vp, c_vp, c_u32, c_vp, c_vp, c_sz, c_vp]),
     "ngp_field_train_saved_bytes": (c_sz, [c_u32]),
     "ngp_field_train_workspace": (c_sz, [c_u32]),
     "ngp_field_train_forward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -166,9 +166,9 @@ def test_renderer_update_extra_state_end_to_end(oracle, dev):
     # against the oracle, with this renderer's own density as the oracle's density_fn
     ren = make(3)
 
-    def density_fn(p):
+    def density_fn(p):                                           # the GPU's own sigmas, by the route update_extra_state takes (NGPFieldFF.density_sigma)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            return ren.density(t(p, dev))["sigma"].float().cpu().numpy()
+            return ren.field.density_sigma(t(p, dev)).float().cpu().numpy()
 
     H, cas = 128, 2
     rnd = CO.grid_update_randoms(3, 0, cas, H, partial=False)
@@ -181,3 +181,24 @@ def test_renderer_update_extra_state_end_to_end(oracle, dev):
     an, _ = W.bitfield_from_grid(W.density_grid())
     x, y = np.unpackbits(an, bitorder="little").astype(bool), np.unpackbits(bf2, bitorder="little").astype(bool)
     assert (x & y).sum() > 0.6 * x.sum()
+
+
+def test_density_sigma_equals_the_one_launch_field_and_the_op_chain(dev):
+    """NGPFieldFF.density_sigma (ngp_field_density: level-by-level encode + the density net alone) against forward_fused (same logits, same exp: bit for bit)
+    and against the op chain under autocast (same logits; torch.exp against ngp_expf: 3e-7), on random points including some outside the box, sizes that are
+    not multiples of 32, and empty input"""
+    from ngp import workload as W
+    from ngp.field import NGPFieldFF
+    field = NGPFieldFF(bound=W.BOUND).to(dev).load_arrays(W.make_model(0)).eval()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for M in (1, 37, 4096, 100001):
+        x = ((torch.rand(M, 3, generator=g) * 2 - 1) * W.BOUND * 1.05).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1).to(dev)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            s_fused = field.density_sigma(x)
+            s_chain = field.density(x)["sigma"].float()
+        s_one, _ = field.forward_fused(x, d, density_scale=1.0)
+        assert s_fused.shape == (M,) and torch.equal(s_fused, s_one)
+        np.testing.assert_allclose(s_fused.cpu().numpy(), s_chain.cpu().numpy(), rtol=3e-7)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert field.density_sigma(torch.zeros(0, 3, device=dev)).shape == (0,)
