@@ -94,6 +94,7 @@ int ngp_march_rays_train_filled(const float* rays_o, const float* rays_d, const 
  * points per step, csrc/raymarching.hip: k_march_train_count_wave) instead of one lane per ray.  Same samples, counts and order either way;
  * returns the previous setting. */
 int ngp_march_set_wave_per_ray(int enabled);   /* also selects the wave-per-ray kernels of ngp_composite_rays_train_* */
+int ngp_composite_set_scan(int enabled);       /* wave-per-ray compositors: chains as lane scans (1, default) or every lane running the recurrence (0); returns the previous setting */
 
 /* raymarching.h:14 composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
 int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,

@@ -799,13 +799,195 @@ __global__ __launch_bounds__(64 * RM_WAVES_PER_BLOCK) void k_composite_train_bwd
     }
 }
 
+// ---------------------------------------------------------------------------
+// The wave-per-ray compositors again, with the serial part cut to what IS serial (round 4).
+//
+// Above, every lane of the wave executes the whole recurrence on broadcast values: ~20 wave-instructions per sample, and a training batch's launch lasts as
+// long as its longest rays' chains (up to 1,024 samples on the early grid) times the four waves that share a SIMD.  But only two things are serial, and
+// bit-exactness only asks that each quantity be formed by the SAME operations in the SAME order as kernel_composite_rays_train_* (raymarching.cu:506-688):
+//   * T_j = ((T_in (1 - a_0)) (1 - a_1)) ... : one multiply per sample.  Lane j gets its T_j from a 64-step chain in which step j multiplies the lanes > j
+//     by (1 - a_j) -- the exec mask shifts left by one lane per step (1 SALU), the factor comes from v_readlane: 2 VALU per sample (rm_chain64; t, the running
+//     sum of deltas[.][1], rides the same loop for 2 more);
+//   * the sums ws, depth, r, g, b are sequential ADDITIONS of per-sample terms w_j, w_j t_j, w_j c_j that the 64 lanes form in parallel: each sum is one
+//     lane's chain of 64 adds over a row the wave parks in LDS (five lanes work at once); the backward needs the running sums r_j, g_j, b_j themselves:
+//     three lanes form them in place and hand them back through LDS.
+// Terms behind the sample on which T falls below 1e-4 are +0 (x + 0 = x exactly), so the early exit needs no branch inside a chunk.  ~6 wave-instructions
+// per sample instead of ~20; same bits (tests/test_gpu_raymarching.py compares every variant with the oracle).
+// ---------------------------------------------------------------------------
+#define RM_REP8(M, b) M(b##0) M(b##1) M(b##2) M(b##3) M(b##4) M(b##5) M(b##6) M(b##7)
+#define RM_REP64(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) RM_REP8(M, 1) M(18) M(19) RM_REP8(M, 2) M(28) M(29) RM_REP8(M, 3) M(38) M(39) \
+                    RM_REP8(M, 4) M(48) M(49) RM_REP8(M, 5) M(58) M(59) M(60) M(61) M(62) M(63)
+#define RM_CHAIN_T_STEP(j) "v_readlane_b32 s90, %[om], " #j "\n s_lshl_b64 exec, exec, 1\n v_mul_f32 %[T], s90, %[T]\n"
+#define RM_CHAIN_TT_STEP(j) "v_readlane_b32 s90, %[om], " #j "\n v_readlane_b32 s91, %[d1], " #j "\n v_add_f32 %[t], s91, %[t]\n s_lshl_b64 exec, exec, 1\n v_mul_f32 %[T], s90, %[T]\n"
+
+// in: T, t = the chains' values before this chunk (the same in every lane), om = 1 - alpha and d1 of this lane's sample (1 and 0 on lanes without one).
+// out: lane L holds T before its sample = ((T om_0) om_1) ... om_{L-1}, and t including its sample = ((t + d1_0) + d1_1) ... + d1_L.
+// Call with all 64 lanes active.  (Inline assembly is opaque to the compiler's hazard recogniser: the s_nop covers "VALU writes a VGPR, v_readlane
+// reads it" for whatever instruction precedes the block; inside it no v_readlane source is written and SALU writes of exec need no wait before a VALU.)
+__device__ __forceinline__ void rm_chain64(float om, float d1, float& T, float& t) {
+    asm volatile("s_mov_b64 s[92:93], exec\n s_nop 1\n" RM_REP64(RM_CHAIN_TT_STEP) "s_mov_b64 exec, s[92:93]\n"
+                 : [T] "+v"(T), [t] "+v"(t) : [om] "v"(om), [d1] "v"(d1) : "s90", "s91", "s92", "s93", "scc");
+}
+__device__ __forceinline__ void rm_chain64(float om, float& T) {
+    asm volatile("s_mov_b64 s[92:93], exec\n s_nop 1\n" RM_REP64(RM_CHAIN_T_STEP) "s_mov_b64 exec, s[92:93]\n"
+                 : [T] "+v"(T) : [om] "v"(om) : "s90", "s92", "s93", "scc");
+}
+__device__ __forceinline__ void rm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+static constexpr uint32_t RM_SCAN_ROW = 68;                              // floats per LDS row: 16-byte aligned, rows on different banks
+
+__global__ __launch_bounds__(64 * RM_WAVES_PER_BLOCK) void k_composite_train_fwd_scan(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                                    const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                                    uint32_t M, uint32_t N, float* __restrict__ weights_sum,
+                                                                                    float* __restrict__ depth, float* __restrict__ image) {
+    __shared__ __attribute__((aligned(16))) float lds_rows[RM_WAVES_PER_BLOCK][5][RM_SCAN_ROW];
+    const uint32_t wib = threadIdx.x >> 6;
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES_PER_BLOCK + wib));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        if (lane == 0) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[3ull * index] = 0; image[3ull * index + 1] = 0; image[3ull * index + 2] = 0;
+        }
+        return;
+    }
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3ull * offset;
+    const float* dl = deltas + 2ull * offset;
+    float (*rows)[RM_SCAN_ROW] = lds_rows[wib];
+    const uint32_t q = lane < 5u ? lane : 0u;                            // lanes 0..4 own the sums ws, depth, r, g, b
+    float T = 1.0f, t = 0.0f, acc = 0.0f;
+    bool done = false;
+    for (uint32_t k0 = 0; k0 < num_steps && !done; k0 += 64) {
+        const bool valid = k0 + lane < num_steps;
+        const uint32_t k = valid ? k0 + lane : num_steps - 1;
+        const float sv = s[k], d0 = dl[2 * k], d1 = dl[2 * k + 1], c0 = c[3 * k], c1 = c[3 * k + 1], c2 = c[3 * k + 2];
+        const float alpha = 1.0f - ngp_expf(-sv * d0);
+        const float om = valid ? 1.0f - alpha : 1.0f;
+        float Tl = T, tl = t;
+        rm_chain64(om, valid ? d1 : 0.0f, Tl, tl);
+        const float Tafter = Tl * om;                                    // T after this lane's sample
+        const unsigned long long brk = __ballot(valid && Tafter < 1e-4f);
+        const bool inc = valid && (brk == 0ull || lane <= (uint32_t)__builtin_ctzll(brk));   // the sample on which T drops below 1e-4 still counts
+        const float w = alpha * Tl;
+        rows[0][lane] = inc ? w : 0.0f;
+        rows[1][lane] = inc ? w * tl : 0.0f;
+        rows[2][lane] = inc ? w * c0 : 0.0f;
+        rows[3][lane] = inc ? w * c1 : 0.0f;
+        rows[4][lane] = inc ? w * c2 : 0.0f;
+        rm_wave_sync();
+        {
+            const float4* row = reinterpret_cast<const float4*>(rows[q]);
+            float x[64];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) { const float4 v = row[i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; }
+            #pragma unroll
+            for (int j = 0; j < 64; j++) acc += x[j];
+        }
+        rm_wave_sync();                                                  // the rows are rewritten by the next chunk
+        done = brk != 0ull;
+        T = rm_bcast(Tafter, 63);
+        t = rm_bcast(tl, 63);
+    }
+    const float ws = rm_bcast(acc, 0), d = rm_bcast(acc, 1), r = rm_bcast(acc, 2), g = rm_bcast(acc, 3), b = rm_bcast(acc, 4);
+    if (lane == 0) {
+        weights_sum[index] = ws; depth[index] = d;
+        image[3ull * index] = r; image[3ull * index + 1] = g; image[3ull * index + 2] = b;
+    }
+}
+
+__global__ __launch_bounds__(64 * RM_WAVES_PER_BLOCK) void k_composite_train_bwd_scan(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+                                                                                    const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                                    const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                                    const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                                    uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
+                                                                                    float* __restrict__ grad_rgbs) {
+    __shared__ __attribute__((aligned(16))) float lds_rows[RM_WAVES_PER_BLOCK][3][RM_SCAN_ROW];
+    const uint32_t wib = threadIdx.x >> 6;
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES_PER_BLOCK + wib));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3ull * n], offset = (uint32_t)rays[3ull * n + 1], num_steps = (uint32_t)rays[3ull * n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float g0 = grad_image[3ull * index], g1 = grad_image[3ull * index + 1], g2 = grad_image[3ull * index + 2];
+    const float rf = image[3ull * index], gf = image[3ull * index + 1], bf = image[3ull * index + 2], wsf = weights_sum[index];
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3ull * offset;
+    const float* dl = deltas + 2ull * offset;
+    float* gs = grad_sigmas + offset;
+    float* gc = grad_rgbs + 3ull * offset;
+    float (*rows)[RM_SCAN_ROW] = lds_rows[wib];
+    const uint32_t q = lane < 3u ? lane : 0u;                            // lanes 0..2 own the running sums r, g, b
+    float T = 1.0f, acc = 0.0f;
+    bool done = false;
+    for (uint32_t k0 = 0; k0 < num_steps && !done; k0 += 64) {
+        const bool valid = k0 + lane < num_steps;
+        const uint32_t k = valid ? k0 + lane : num_steps - 1;
+        const float sv = s[k], d0 = dl[2 * k], c0 = c[3 * k], c1 = c[3 * k + 1], c2 = c[3 * k + 2];
+        const float alpha = 1.0f - ngp_expf(-sv * d0);
+        const float om = valid ? 1.0f - alpha : 1.0f;
+        float Tl = T;
+        rm_chain64(om, Tl);
+        const float mT = Tl * om;                                        // T after this lane's sample
+        const unsigned long long brk = __ballot(valid && mT < 1e-4f);
+        const uint32_t jstar = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
+        const bool inc = valid && lane <= jstar;                        // the running sums include the sample on which T drops below 1e-4 ...
+        const bool mine = valid && lane < jstar;                        // ... but it gets no gradient, like every later one (raymarching.cu:661)
+        const float mw = alpha * Tl;
+        rows[0][lane] = inc ? mw * c0 : 0.0f;
+        rows[1][lane] = inc ? mw * c1 : 0.0f;
+        rows[2][lane] = inc ? mw * c2 : 0.0f;
+        rm_wave_sync();
+        {
+            float4* row = reinterpret_cast<float4*>(rows[q]);
+            float x[64];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) { const float4 v = row[i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; }
+            x[0] = acc + x[0];
+            #pragma unroll
+            for (int j = 1; j < 64; j++) x[j] = x[j - 1] + x[j];
+            acc = x[63];
+            rm_wave_sync();                                              // every lane has read its row before lanes 0..2 overwrite theirs
+            if (lane < 3u) {
+                #pragma unroll
+                for (int i = 0; i < 16; i++) row[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+            }
+        }
+        rm_wave_sync();
+        const float mr = rows[0][lane], mg = rows[1][lane], mb = rows[2][lane];
+        if (mine) {
+            gc[3 * k] = g0 * mw; gc[3 * k + 1] = g1 * mw; gc[3 * k + 2] = g2 * mw;
+            gs[k] = d0 * (g0 * (mT * c0 - (rf - mr)) +
+                          g1 * (mT * c1 - (gf - mg)) +
+                          g2 * (mT * c2 - (bf - mb)) +
+                          gws * (1.0f - wsf));
+        }
+        rm_wave_sync();                                                  // the rows are rewritten by the next chunk
+        done = brk != 0ull;
+        T = rm_bcast(mT, 63);
+    }
+}
+
+// process-wide switch between the two wave-per-ray compositors (tests compare both with the oracle; A/B timing)
+static std::atomic<int> rm_scan_composite_enabled{1};
+extern "C" int ngp_composite_set_scan(int enabled) { return rm_scan_composite_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
+
 extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                                 uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image, void* stream) {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null sample pointer");
     if (N == 0) return NGP_OK;
-    if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed))
+    if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed) && rm_scan_composite_enabled.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL(k_composite_train_fwd_scan, dim3(ngp_div_up(N, RM_WAVES_PER_BLOCK)), dim3(64 * RM_WAVES_PER_BLOCK), 0, (hipStream_t)stream,
+                           sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    else if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed))
         hipLaunchKernelGGL(k_composite_train_fwd_wave, dim3(ngp_div_up(N, RM_WAVES_PER_BLOCK)), dim3(64 * RM_WAVES_PER_BLOCK), 0, (hipStream_t)stream,
                            sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
     else
@@ -823,7 +1005,10 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
     NGP_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, "composite_rays_train_backward: null pointer");
     NGP_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), "composite_rays_train_backward: null sample pointer");
     if (N == 0) return NGP_OK;
-    if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed))
+    if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed) && rm_scan_composite_enabled.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL(k_composite_train_bwd_scan, dim3(ngp_div_up(N, RM_WAVES_PER_BLOCK)), dim3(64 * RM_WAVES_PER_BLOCK), 0, (hipStream_t)stream,
+                           grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    else if (N < RM_WAVE_PER_RAY_MAX && rm_wave_march_enabled.load(std::memory_order_relaxed))
         hipLaunchKernelGGL(k_composite_train_bwd_wave, dim3(ngp_div_up(N, RM_WAVES_PER_BLOCK)), dim3(64 * RM_WAVES_PER_BLOCK), 0, (hipStream_t)stream,
                            grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
     else

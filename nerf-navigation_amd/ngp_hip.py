@@ -37,6 +37,7 @@ _SIGNATURES = {
     "ngp_march_rays_train_filled": (c_int, [c_vp, c_vp, c_vp, c_f32, c_f32, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp,
                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_sz, c_vp]),
     "ngp_march_set_wave_per_ray": (c_int, [c_int]),
+    "ngp_composite_set_scan": (c_int, [c_int]),
     "ngp_composite_rays_train_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp]),
     "ngp_composite_rays_train_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_march_rays": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,

@@ -272,25 +272,32 @@ def test_march_rays_train_matches_iterated_march_rays(oracle, scene):
         assert np.array_equal(x1[:k].view(np.uint32), x_r[off:off + cnt].view(np.uint32))
 
 
-@pytest.mark.parametrize("wave_per_ray", [1, 0], ids=["wave_per_ray", "lane_per_ray"])
-def test_composite_rays_train_forward_backward(oracle, dev, scene, wave_per_ray):
-    """both kernel shapes (one wave per ray for training-sized batches, one lane per ray otherwise) against the oracle, bit for bit"""
+@pytest.mark.parametrize("density", [50.0, 150.0], ids=["budget", "every_sample"])
+@pytest.mark.parametrize("shape", ["scan", "wave", "lane"])
+def test_composite_rays_train_forward_backward(oracle, dev, scene, shape, density):
+    """all three kernel shapes (one wave per ray with the chains as lane scans -- the default for training-sized batches --, one wave per ray with every
+    lane running the recurrence, one lane per ray) against the oracle, bit for bit.  "budget": perturbed rays under a sample budget that drops some of them;
+    "every_sample": rays of up to 525 samples, on a twelfth of which T falls below 1e-4 -- in the first chunk of 64 lanes, the second, or a later one."""
     import ngp_hip
-    import raymarching
-    previous = ngp_hip.lib().ngp_march_set_wave_per_ray(wave_per_ray)
+    lib = ngp_hip.lib()
+    wave, scan = lib.ngp_march_set_wave_per_ray(shape != "lane"), lib.ngp_composite_set_scan(shape == "scan")
     try:
-        _composite_rays_train_forward_backward(oracle, dev, scene)
+        _composite_rays_train_forward_backward(oracle, dev, scene, density)
     finally:
-        ngp_hip.lib().ngp_march_set_wave_per_ray(previous)
+        lib.ngp_march_set_wave_per_ray(wave)
+        lib.ngp_composite_set_scan(scan)
 
 
-def _composite_rays_train_forward_backward(oracle, dev, scene):
+def _composite_rays_train_forward_backward(oracle, dev, scene, density):
     import raymarching
     o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
-    x, _, l, rays = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, None, 30000, True, 128, False, 0.0, 1024)
+    if density == 50.0:
+        x, _, l, rays = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, None, 30000, True, 128, False, 0.0, 1024)
+    else:
+        x, _, l, rays = oracle.march_rays_train(o, d, BOUND, bf, CAS, H, nears, fars, None, -1, False, 128, True, 0.0, 1024)    # force_all_rays
     rng = np.random.default_rng(0)
     M = x.shape[0]
-    sig = (50.0 * np.exp(-3.0 * (x ** 2).sum(1)) * rng.uniform(0.5, 1.5, M)).astype(np.float32)
+    sig = (density * np.exp(-3.0 * (x ** 2).sum(1)) * rng.uniform(0.5, 1.5, M)).astype(np.float32)
     rgb = rng.uniform(0, 1, size=(M, 3)).astype(np.float32)
     ws_r, dp_r, im_r = oracle.composite_rays_train_forward(sig, rgb, l, rays)
 
@@ -299,7 +306,10 @@ def _composite_rays_train_forward_backward(oracle, dev, scene):
     assert_same_bits(ws, ws_r, "weights_sum")
     assert_same_bits(dp, dp_r, "depth")
     assert_same_bits(im, im_r, "image")
-    assert (rays[:, 1] + rays[:, 2] >= M).any() and (rays[:, 2] == 0).any()     # dropped and empty rays present
+    if density == 50.0:
+        assert (rays[:, 1] + rays[:, 2] >= M).any() and (rays[:, 2] == 0).any()     # dropped and empty rays present
+    else:
+        assert (rays[:, 2] > 192).sum() > 400 and (ws_r > 0.9999).sum() > 100         # long rays; early exits
 
     g_ws = rng.normal(size=ws_r.shape).astype(np.float32)
     g_im = rng.normal(size=im_r.shape).astype(np.float32)
