@@ -287,7 +287,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
 // in order (du = the lattice spacing of that window).  Returns the number of samples found.  Requires dt_gamma == 0 and an exact grid (m.blocks_per_level != 0).
 template <class Emit>
 __device__ __forceinline__ uint32_t rm_wave_march(const ngp_march_t& m, const uint32_t* __restrict__ lds_coarse, uint32_t coarse_words,
-                                                  float t_start, float far, uint32_t max_new, Emit&& emit) {
+                                                  float t_start, float far, uint32_t max_new, bool replay_only, Emit&& emit) {
     const int lane = (int)(threadIdx.x & 63u);
     const float dtc = ngp_clampf(0.0f, m.dt_min, m.dt_max);            // dt(t) for dt_gamma == 0
     float t_cur = t_start;
@@ -329,11 +329,32 @@ __device__ __forceinline__ uint32_t rm_wave_march(const ngp_march_t& m, const ui
         const unsigned long long valid_mask = __ballot(valid);
         const unsigned long long occ_mask = __ballot(valid && occ);
         const unsigned long long heads = __ballot(lane == 0 || cell != prev_cell);       // bit k: lane k starts a run of one cell
-        // ---- replay of the reference's control flow over the window ----
+        // ---- the reference's control flow over the window ----
         unsigned long long smask = 0ull;                               // lattice points that are samples
-        int after = -1;                                                // candidates are lanes > after
         uint32_t room = max_new - count;
-        for (int it = 0; it < 66 && room > 0; it++) {
+        // Almost always the tested points are exactly: the first lattice point of every cell's run, and every point of an occupied run.  Each lane
+        // that heads an empty run checks that guess against the comparisons the replay below would make (the next point at or beyond its exit
+        // parameter is the next run's head, the point before that is not); one ballot accepts the whole window, anything else is replayed.
+        const unsigned long long cand0 = valid_mask & __ballot(tk >= t_skip);
+        bool replay = cand0 != 0ull && room > 0;
+        if (replay && !replay_only) {
+            const int j0 = __builtin_ctzll(cand0);                     // first tested point of the window
+            const int nv = 64 - __builtin_clzll(valid_mask);           // valid lanes are 0 .. nv - 1 (tk is monotone)
+            const unsigned long long H = (heads | (1ull << j0)) & cand0;
+            const unsigned long long S = cand0 & occ_mask;
+            const unsigned long long later = lane >= 63 ? 0ull : (H & (~0ull << (lane + 1)));
+            const int nh = later ? __builtin_ctzll(later) : nv;        // the next run's head (nv: none in this window)
+            const float t_nh = t_cur + (float)nh * du, t_before = t_cur + (float)(nh - 1) * du;      // those lanes' own tk
+            const bool bad = (((H & ~occ_mask) >> lane) & 1ull) && ((nh < nv && !(t_nh >= tt)) || (nh - 1 > lane && t_before >= tt));
+            if (__ballot(bad) == 0ull && (uint32_t)__popcll(S) <= room && valid_mask == (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull))) {
+                smask = S;
+                const int hl = 63 - __builtin_clzll(H);                // the last run decides what the next window inherits
+                t_skip = ((occ_mask >> hl) & 1ull) ? -__builtin_inff() : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), hl));
+                replay = false;
+            }
+        }
+        int after = -1;                                                // candidates are lanes > after
+        for (int it = 0; replay && it < 66 && room > 0; it++) {
             const unsigned long long low = after < 0 ? 0ull : (after >= 63 ? ~0ull : ((2ull << after) - 1ull));
             const unsigned long long cand = valid_mask & __ballot(tk >= t_skip) & ~low;
             if (!cand) break;
@@ -366,14 +387,14 @@ __device__ __forceinline__ uint32_t rm_wave_march(const ngp_march_t& m, const ui
 }
 
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_args a, int* __restrict__ rays, const int* __restrict__ counter,
-                                                                     float* __restrict__ tbuf) {
+                                                                     float* __restrict__ tbuf, uint32_t replay_only) {
     const uint32_t* lds_coarse = rm_stage_coarse(a);
     const uint32_t n = blockIdx.x;
     const int lane = (int)threadIdx.x;
     ngp_march_t m;
     m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
     float* tb = tbuf + (size_t)n * a.max_steps;
-    const uint32_t count = rm_wave_march(m, lds_coarse, a.coarse_words, train_t0(m, a.nears[n], n, a.perturb), a.fars[n], a.max_steps,
+    const uint32_t count = rm_wave_march(m, lds_coarse, a.coarse_words, train_t0(m, a.nears[n], n, a.perturb), a.fars[n], a.max_steps, replay_only != 0u,
                                          [&](uint32_t found, unsigned long long smask, float tk, float) {
         if ((smask >> lane) & 1ull) tb[found + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull))] = tk;    // the samples' parameters, in order
     });
@@ -527,7 +548,9 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_fill(march_args a,
 // validation switch: 0 = always march one lane per ray (tests compare the two count passes)
 static std::atomic<int> rm_wave_march_enabled{1};
 static constexpr uint32_t RM_WAVE_PER_RAY_MAX = 1u << 17;      // composite: from this many rays on, one lane per ray fills the chip by itself
-extern "C" int ngp_march_set_wave_per_ray(int enabled) { return rm_wave_march_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
+// 0: one lane per ray; 1: one wave per ray; 2: one wave per ray, every window through the serial replay (the path the one-ballot acceptance of
+// rm_wave_march falls back to: selectable so that tests exercise it on whole scenes)
+extern "C" int ngp_march_set_wave_per_ray(int enabled) { return rm_wave_march_enabled.exchange(enabled < 0 || enabled > 2 ? 1 : enabled, std::memory_order_relaxed); }
 
 static size_t rm_train_ws_base(uint32_t N) { return (sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4) + 255) & ~(size_t)255; }
 
@@ -568,9 +591,10 @@ static int rm_march_rays_train(const float* rays_o, const float* rays_d, const u
     const size_t cbytes = rm_coarse_bytes(grid, C, H);
     if (cbytes) rm_attach_coarse(a, reinterpret_cast<unsigned char*>(workspace) + rm_train_ws_base(N), s);
     // one wave per ray when the lattice is closed-form (constant step) and the sample parameters can be recorded; else one lane per ray
-    const bool wave_per_ray = tbuf && cbytes && dt_gamma == 0.0f && C <= 4 && rm_wave_march_enabled.load(std::memory_order_relaxed);
+    const int wave_mode = rm_wave_march_enabled.load(std::memory_order_relaxed);
+    const bool wave_per_ray = tbuf && cbytes && dt_gamma == 0.0f && C <= 4 && wave_mode != 0;
     if (wave_per_ray) {
-        hipLaunchKernelGGL(k_march_train_count_wave, dim3(N), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, tbuf);
+        hipLaunchKernelGGL(k_march_train_count_wave, dim3(N), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, tbuf, wave_mode == 2 ? 1u : 0u);
         hipLaunchKernelGGL(k_march_train_sum64, dim3(ngp_div_up(nblocks, RM_BLOCK)), dim3(RM_BLOCK), 0, s, rays, counter, N, nblocks, block_sums);
     } else {
         hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, block_sums, tbuf);

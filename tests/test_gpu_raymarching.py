@@ -221,8 +221,8 @@ def test_march_rays_train_with_a_pre_advanced_counter(oracle, dev, scene):
 @pytest.mark.parametrize("max_steps", [1024, 24])
 @pytest.mark.parametrize("perturb", [False, True])
 def test_wave_per_ray_count_pass_equals_lane_per_ray(oracle, dev, perturb, max_steps):
-    """the count pass with one wave per ray (k_march_train_count_wave: 64 lattice points per step, the reference's control flow replayed run by
-    run) against the one-lane-per-ray pass and against the oracle: counts, order and positions bit for bit -- 4,096 camera rays through the S-ring
+    """the count pass with one wave per ray (k_march_train_count_wave: 64 lattice points per step, the reference's control flow accepted by one
+    ballot per window or replayed run by run) against the one-lane-per-ray pass and against the oracle: counts, order and positions bit for bit -- 4,096 camera rays through the S-ring
     grid plus axis-parallel and missing rays, with and without jitter, and with a max_steps small enough that the cap cuts rays short"""
     import ngp_hip
     import raymarching
@@ -239,7 +239,7 @@ def test_wave_per_ray_count_pass_equals_lane_per_ray(oracle, dev, perturb, max_s
     c_ref = np.zeros(2, np.int32)
     x_r, _, l_r, r_r = oracle.march_rays_train(o, d, 2.0, bf, 2, 128, nears, fars, c_ref, -1, perturb, 128, False, 0.0, max_steps)
     out = {}
-    for wave in (1, 0):
+    for wave in (1, 2, 0):                                            # 2: every window through the serial replay (the fallback of 1's one-ballot acceptance)
         ngp_hip.lib().ngp_march_set_wave_per_ray(wave)
         try:
             cnt = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -248,7 +248,7 @@ def test_wave_per_ray_count_pass_equals_lane_per_ray(oracle, dev, perturb, max_s
         finally:
             ngp_hip.lib().ngp_march_set_wave_per_ray(1)
     for k in range(5):
-        assert torch.equal(out[1][k], out[0][k]), k
+        assert torch.equal(out[1][k], out[0][k]) and torch.equal(out[2][k], out[0][k]), k
     assert_same_bits(out[1][4], c_ref, "counter")
     assert_same_bits(out[1][3], r_r, "rays")
     assert_same_bits(out[1][0], x_r, "xyzs")
