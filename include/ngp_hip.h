@@ -218,6 +218,12 @@ size_t ngp_grid_scatter_binned_workspace(uint32_t B, uint32_t L);
 int ngp_grid_scatter_binned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                             uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
                             int out_dtype, float out_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a LISTED batch: gradient row i (of every level) belongs to the sample at inputs[list[i]], i < *list_count <= B; list and list_count are
+ * device memory read by the kernels (no synchronisation).  B <= 2^22. */
+int ngp_grid_scatter_binned_listed(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                   uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
+                                   int out_dtype, float out_scale, const uint32_t* list, const uint32_t* list_count,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 /* The same in two steps: phase 1 bins all levels (grad_embeddings unused), phase 2 sums levels [level_lo, level_hi) into their rows of grad_embeddings;
  * any number of phase-2 calls after one phase-1 call (same workspace, same stream).  Lets the data-parallel gradient exchange all-reduce one group of
  * levels while the next is summed.  B <= 2^22. */
@@ -225,6 +231,10 @@ int ngp_grid_scatter_binned_phase(int phase, const void* grad, const float* inpu
                                   uint32_t B, uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H, uint32_t max_level_rows,
                                   uint32_t gridtype, int align_corners, int out_dtype, float out_scale, void* workspace, size_t workspace_bytes,
                                   void* stream);
+int ngp_grid_scatter_binned_phase_listed(int phase, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                         uint32_t B, uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H, uint32_t max_level_rows,
+                                         uint32_t gridtype, int align_corners, int out_dtype, float out_scale, const uint32_t* list,
+                                         const uint32_t* list_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* optimiser step of the training loop                                       */
@@ -376,11 +386,15 @@ int ngp_field_forward_half(const ngp_field_t* field_host, const float* xyzs, con
  * forward: as ngp_field_forward, and keeps the encoded features of every sample (64 B each, level-major [16][M rounded up to 32] half2) in
  *   `saved` (ngp_field_train_saved_bytes(M) bytes) -- the only activation kept; both networks are recomputed in the backward.
  * backward: grad_sigmas [M], grad_rgbs [M,3] f32 (gradients of the forward's outputs) ->
- *   grad_enc [16][M][2] f16, level-major: d(loss)/d(encoded features), the `grad` argument of ngp_grid_encode_backward;
+ *   grad_enc [16][M][2] f16, level-major: d(loss)/d(encoded features), the `grad` argument of ngp_grid_encode_backward / ngp_grid_scatter_binned;
  *   grad_sigma_weights [7168], grad_color_weights [11264] f32 in FFMLP's weight layout, rounded to half like the reference's grad_weights.
+ *   live_only != 0: the kernels work on the samples whose incoming gradients are not all +0 (bit pattern) and nothing else -- behind the compositor's
+ *   early exit half of a converged batch gets none, and everything such a sample would contribute is +0 bit for bit.  grad_enc is then written in
+ *   LIST order: row i of every level belongs to sample list[i], i < *count (rows from *count on are not written); ngp_field_train_live_list returns
+ *   the two device pointers (into `workspace`), ngp_grid_scatter_binned_listed takes them.  live_only == 0: every sample, rows in sample order.
  *   field_host must describe the same half copies the forward used.  workspace: ngp_field_train_workspace(M) bytes, contents arbitrary
- *   (per-workgroup partial sums of the weight gradients, added in a fixed order: the gradients are bitwise reproducible; nothing to clear,
- *   ngp_field_train_workspace(0) == 0). */
+ *   (per-workgroup partial sums of the weight gradients, added in a fixed order: the gradients are bitwise reproducible; the live list; nothing to
+ *   clear, ngp_field_train_workspace(0) == 0). */
 /* Density only (sigma = exp(h0) * field.density_scale) for M points in two launches: the level-by-level encoder of the training forward, then the
  * density net on the matrix cores -- what the occupancy-grid refresh asks of the field (nerf/renderer.py:478-486,511-517 `self.density(xyzs)['sigma']`
  * on millions of random cell positions).  Same logits as ngp_field_forward.  workspace: ngp_field_density_workspace(M) bytes. */
@@ -390,12 +404,15 @@ size_t ngp_field_train_saved_bytes(uint32_t M);
 /* forward in two passes (default: the encoder level by level, one level's table live in L2 at a time, then the networks) or in one launch;
  * same values and the same `saved` layout either way; returns the previous setting (process-wide: A/B timing, tests). */
 int ngp_field_train_set_two_pass(int enabled);
+int ngp_field_train_set_live_only(int enabled);   /* 0: ngp_field_train_backward(live_only = 1) lists every sample (A/B timing, tests); returns the previous setting */
 size_t ngp_field_train_workspace(uint32_t M);
 int ngp_field_train_forward(const ngp_field_t* field_host, const float* xyzs, const float* dirs, uint32_t M,
                             float* sigmas, float* rgbs, void* saved, size_t saved_bytes, void* stream);
 int ngp_field_train_backward(const ngp_field_t* field_host, const void* saved, const float* dirs, uint32_t M,
                              const float* grad_sigmas, const float* grad_rgbs, void* grad_enc,
-                             float* grad_sigma_weights, float* grad_color_weights, void* workspace, size_t workspace_bytes, void* stream);
+                             float* grad_sigma_weights, float* grad_color_weights, void* workspace, size_t workspace_bytes, int live_only,
+                             void* stream);
+int ngp_field_train_live_list(void* workspace, uint32_t M, const uint32_t** list, const uint32_t** count);
 
 /* One whole frame of NeRFRenderer.run_cuda's inference branch (nerf/renderer.py:325-374) in one launch:
  * near/far, occupancy march, field evaluation and compositing per ray, with no intermediate tensors.

@@ -406,7 +406,8 @@ template <int PART>
 __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params P, const uint32_t* __restrict__ enc, const float* __restrict__ dirs, uint32_t M,
                                                                        const float* __restrict__ grad_sigmas, const float* __restrict__ grad_rgbs,
                                                                        ngp_h4* __restrict__ grad_outs, _Float16* __restrict__ grad_enc,
-                                                                       float* __restrict__ wgrad_ws) {
+                                                                       float* __restrict__ wgrad_ws, const uint32_t* __restrict__ live_count,
+                                                                       const uint32_t* __restrict__ live_list) {
     constexpr int NACC = PART == 0 ? FT_NACC_COLOR : FT_NACC_SIGMA;
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
     ngp_h8* lds_w = reinterpret_cast<ngp_h8*>(rf_smem);
@@ -423,18 +424,30 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
     for (int k = 0; k < NACC; k++) acc[k] = zero;
 
     const uint32_t wave = (blockIdx.x * RF_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (RF_BLOCK / 64);
-    const uint32_t npairs = (M + 31) >> 5, Mp = npairs << 5;
+    // Only the LIVE samples are worked on: those with a non-zero incoming gradient, compacted in order by k_ft_live_count / k_ft_live_write (below).
+    // On a converged scene half of a batch's samples lie behind the compositor's early exit (tools/zero_grad_fraction.py: 0.46-0.59 of them).  A pair
+    // is 32 consecutive entries of the list; grad_outs is in list order, everything else is addressed through the list.
+    const uint32_t nlive = live_count[0];
+    const uint32_t npairs = (nlive + 31) >> 5, Mp = ((M + 31) >> 5) << 5;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;                            // a pair's slot past the end of the list (>= M: nothing loaded, nothing stored)
+    auto samples_of = [&](uint32_t pr, uint32_t* out) {
+        #pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const uint32_t cp = pr * 32 + 16 * n + s;
+            out[n] = (pr < npairs && cp < nlive) ? live_list[cp] : NONE;
+        }
+    };
     // What a pair reads from memory, fetched ONE PAIR AHEAD: the kernel runs one wave per SIMD (400+ registers), so nothing else hides the ~2 us between a
     // pair's first load and its first use -- 55 pairs per wave on an early 1.8 M-point batch.  The next pair's loads are issued before this pair's two
-    // MFMA chains and have landed when the loop comes round (22 / 12 registers).
+    // MFMA chains and have landed when the loop comes round (22 / 12 registers); its list entries were loaded one iteration earlier still.
     struct ft_raw { ngp_h8 x[2]; float d[2][3], gs[2], gc[2][3]; ngp_h4 go[2]; };
-    auto fetch = [&](uint32_t pr) {
+    auto fetch = [&](uint32_t pr, const uint32_t* idx) {
         ft_raw r;
         #pragma unroll
         for (int n = 0; n < 2; n++) {
-            const uint32_t mn = pr * 32 + 16 * n + s;
+            const uint32_t mn = idx[n];
             const uint64_t mm = mn < M ? mn : 0;
-            r.x[n] = ft_enc_load(enc, Mp, mn, g);
+            r.x[n] = ft_enc_load(enc, Mp, (uint32_t)mm, g);
             if constexpr (PART == 0) {
                 #pragma unroll
                 for (int k = 0; k < 3; k++) r.d[n][k] = dirs[3 * mm + k];
@@ -449,16 +462,20 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
         return r;
     };
     ft_raw cur;
-    if (wave < npairs) cur = fetch(wave);
+    uint32_t icur[2], inxt[2], inn[2];
+    samples_of(wave, icur);
+    samples_of(wave + nwaves, inxt);
+    if (wave < npairs) cur = fetch(wave, icur);
     for (uint32_t pair = wave; pair < npairs; pair += nwaves) {
         ft_raw nxt = cur;
-        if (pair + nwaves < npairs) nxt = fetch(pair + nwaves);       // (wave-uniform)
+        if (pair + nwaves < npairs) nxt = fetch(pair + nwaves, inxt);   // (wave-uniform)
+        samples_of(pair + 2 * nwaves, inn);
         ngp_h8 x[2];
         ngp_h4 shq[2];
         uint32_t m[2];
         #pragma unroll
         for (int n = 0; n < 2; n++) {
-            m[n] = pair * 32 + 16 * n + s;
+            m[n] = icur[n];
             if constexpr (PART == 0) {
                 float sh[16];
                 sh_eval<4>(cur.d[n][0], cur.d[n][1], cur.d[n][2], P.shn, sh);
@@ -599,16 +616,19 @@ __global__ __launch_bounds__(RF_BLOCK, 1) void k_field_train_backward(rf_params 
                         if (m[n] < M) {
                             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                             const uint32_t level = 8 * t + 2 * g;   // rows 4g + r = features 16 t + 4 g + r = levels 8 t + 2 g, + 1
+                            const uint32_t cp = pair * 32 + 16 * n + s;      // list order: the scatter reads the list too
                             h2 lo, hi;
                             lo.x = (_Float16)d[0]; lo.y = (_Float16)d[1]; hi.x = (_Float16)d[2]; hi.y = (_Float16)d[3];
-                            *reinterpret_cast<h2*>(grad_enc + ((size_t)level * M + m[n]) * 2) = lo;
-                            *reinterpret_cast<h2*>(grad_enc + ((size_t)(level + 1) * M + m[n]) * 2) = hi;
+                            *reinterpret_cast<h2*>(grad_enc + ((size_t)level * M + cp) * 2) = lo;
+                            *reinterpret_cast<h2*>(grad_enc + ((size_t)(level + 1) * M + cp) * 2) = hi;
                         }
                     }
                 }
             }
         }
         cur = nxt;
+        icur[0] = inxt[0]; icur[1] = inxt[1];
+        inxt[0] = inn[0]; inxt[1] = inn[1];
     }
 
     // ---- the workgroup's weight gradients: sum the four waves through LDS (fixed order), then this workgroup's row of the partial-sum buffer: plain
@@ -676,9 +696,78 @@ static uint32_t ft_bwd_blocks(uint32_t M) {
     const uint32_t blocks = ngp_div_up((M + 31) >> 5, RF_BLOCK / 64);
     return blocks > 256 ? 256 : blocks;
 }
-// workspace: [per-workgroup f32 weight-gradient partial sums, ft_bwd_blocks(M) x 18,432 | the density-net output gradients of M samples]; nothing to clear
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The live samples of a backward: those whose incoming gradients (d loss / d sigma, d loss / d rgb) are not all +0, listed in order.  Everything a
+// dead sample would contribute is +0 bit for bit (products with +0, matrix-core sums of them on +0 accumulators, ReLU masks, half roundings; a float
+// accumulator is never -0, so x + (+-0) = x), so the backward kernels work on the list alone, and d loss / d(encoded features) is written in LIST
+// order: row i of every level belongs to sample list[i]; the table scatter takes the list along (ngp_grid_scatter_binned_listed) and never sees a
+// dead sample either.  (Only an inf / NaN activation of a dead sample would have poisoned the weight gradients through 0 * inf.)
+//   k_ft_live_count  one thread per sample: the wave's ballot goes to a bitmap, the workgroup's count to counts[chunk]
+//   k_ft_live_write  workgroup c adds up counts[0 .. c) itself (at most 4,096 values) and writes its samples' indices behind them: an ordered
+//                    compaction in two launches with nothing to clear; the last workgroup leaves the total in count[0]
+// ---------------------------------------------------------------------------------------------------------------------------------------
+static constexpr uint32_t FT_LIVE_CHUNK = 1024;
+__global__ __launch_bounds__(FT_LIVE_CHUNK) void k_ft_live_count(const float* __restrict__ grad_sigmas, const float* __restrict__ grad_rgbs, uint32_t M,
+                                                               uint32_t* __restrict__ counts, unsigned long long* __restrict__ bitmap, uint32_t all_live) {
+    __shared__ uint32_t s_cnt[FT_LIVE_CHUNK / 64];
+    const uint32_t tid = threadIdx.x, m = blockIdx.x * FT_LIVE_CHUNK + tid, wave = tid >> 6;
+    uint32_t bits = 0u;
+    if (m < M)
+        bits = all_live | __builtin_bit_cast(uint32_t, grad_sigmas[m]) | __builtin_bit_cast(uint32_t, grad_rgbs[3ull * m]) |
+               __builtin_bit_cast(uint32_t, grad_rgbs[3ull * m + 1]) | __builtin_bit_cast(uint32_t, grad_rgbs[3ull * m + 2]);
+    const unsigned long long word = __ballot(bits != 0u);
+    if ((tid & 63u) == 0u) { bitmap[(size_t)blockIdx.x * (FT_LIVE_CHUNK / 64) + wave] = word; s_cnt[wave] = (uint32_t)__popcll(word); }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        #pragma unroll
+        for (uint32_t w = 0; w < FT_LIVE_CHUNK / 64; w++) c += s_cnt[w];
+        counts[blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(FT_LIVE_CHUNK) void k_ft_live_write(const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ bitmap, uint32_t nchunks,
+                                                               uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_part[FT_LIVE_CHUNK / 64], s_cnt[FT_LIVE_CHUNK / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, chunk = blockIdx.x;
+    uint32_t before = 0;
+    for (uint32_t c = tid; c < chunk; c += FT_LIVE_CHUNK) before += counts[c];
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+    const unsigned long long word = bitmap[(size_t)chunk * (FT_LIVE_CHUNK / 64) + wave];
+    if (lane == 0) { s_part[wave] = before; s_cnt[wave] = (uint32_t)__popcll(word); }
+    __syncthreads();
+    uint32_t base = 0, own = 0;
+    #pragma unroll
+    for (uint32_t w = 0; w < FT_LIVE_CHUNK / 64; w++) { base += s_part[w]; if (w < wave) base += s_cnt[w]; own += s_cnt[w]; }
+    if ((word >> lane) & 1ull) list[base + (uint32_t)__popcll(word & ((1ull << lane) - 1ull))] = chunk * FT_LIVE_CHUNK + tid;
+    if (chunk == nchunks - 1 && tid == 0) {
+        uint32_t total = own;
+        #pragma unroll
+        for (uint32_t w = 0; w < FT_LIVE_CHUNK / 64; w++) total += s_part[w];
+        count[0] = total;
+    }
+}
+
+// workspace: [per-workgroup f32 weight-gradient partial sums, ft_bwd_blocks(M) x 18,432 | the density-net output gradients of the live samples |
+//             live count (256 B) | per-chunk counts | bitmap | list of live samples]; nothing to clear
 static size_t ft_ws_outs_offset(uint32_t M) { return ((size_t)ft_bwd_blocks(M) * FT_WS_FLOATS * sizeof(float) + 255) & ~(size_t)255; }
-extern "C" size_t ngp_field_train_workspace(uint32_t M) { return ft_ws_outs_offset(M) + (size_t)((M + 31) >> 5) * 2 * 64 * sizeof(ngp_h4); }
+static size_t ft_ws_live_offset(uint32_t M) { return ft_ws_outs_offset(M) + (size_t)((M + 31) >> 5) * 2 * 64 * sizeof(ngp_h4); }
+static size_t ft_live_counts_bytes(size_t nch) { return (nch * 4 + 255) & ~(size_t)255; }
+static size_t ft_ws_live_bytes(uint32_t M) {
+    const size_t nch = ngp_div_up(M ? M : 1u, FT_LIVE_CHUNK);
+    return 256 + ft_live_counts_bytes(nch) + nch * (FT_LIVE_CHUNK / 64) * 8 + (((size_t)M + 31) & ~(size_t)31) * 4;
+}
+extern "C" size_t ngp_field_train_workspace(uint32_t M) { return M ? ft_ws_live_offset(M) + ft_ws_live_bytes(M) : 0; }
+// where the last ngp_field_train_backward(.., workspace, .., M) left its list of live samples and their number (device pointers into that workspace)
+extern "C" int ngp_field_train_live_list(void* workspace, uint32_t M, const uint32_t** list, const uint32_t** count) {
+    NGP_REQUIRE(workspace && list && count && M > 0, "field_train_live_list: null pointer or empty batch");
+    unsigned char* base = static_cast<unsigned char*>(workspace) + ft_ws_live_offset(M);
+    const size_t nch = ngp_div_up(M, FT_LIVE_CHUNK);
+    *count = reinterpret_cast<const uint32_t*>(base);
+    *list = reinterpret_cast<const uint32_t*>(base + 256 + ft_live_counts_bytes(nch) + nch * (FT_LIVE_CHUNK / 64) * 8);
+    return NGP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Density only, for a few million INCOHERENT points: the occupancy-grid refresh (nerf/renderer.py:446-531 queries `density(xyzs)['sigma']` on
@@ -795,10 +884,14 @@ extern "C" int ngp_field_train_forward(const ngp_field_t* field_host, const floa
 }
 
 static std::atomic<unsigned> ft_big_lds_set{0};
+// process-wide switch for A/B timing and tests: 0 = the backward treats every sample as live (the list is the identity)
+static std::atomic<int> ft_live_only{1};
+extern "C" int ngp_field_train_set_live_only(int enabled) { return ft_live_only.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int ngp_field_train_backward(const ngp_field_t* field_host, const void* saved, const float* dirs, uint32_t M,
                                         const float* grad_sigmas, const float* grad_rgbs, void* grad_enc,
-                                        float* grad_sigma_weights, float* grad_color_weights, void* workspace, size_t workspace_bytes, void* stream) {
+                                        float* grad_sigma_weights, float* grad_color_weights, void* workspace, size_t workspace_bytes, int live_only,
+                                        void* stream) {
     rf_params P;
     int rc = rf_fill_params("field_train_backward", field_host, P);
     if (rc != NGP_OK) return rc;
@@ -815,12 +908,22 @@ extern "C" int ngp_field_train_backward(const ngp_field_t* field_host, const voi
             ft_big_lds_set.fetch_or(1u << dev, std::memory_order_release);
         }
         const uint32_t blocks = ft_bwd_blocks(M);
-        ngp_h4* grad_outs = reinterpret_cast<ngp_h4*>(static_cast<unsigned char*>(workspace) + ft_ws_outs_offset(M));
+        unsigned char* ws = static_cast<unsigned char*>(workspace);
+        ngp_h4* grad_outs = reinterpret_cast<ngp_h4*>(ws + ft_ws_outs_offset(M));
+        const uint32_t nch = ngp_div_up(M, FT_LIVE_CHUNK);
+        uint32_t* live_count = reinterpret_cast<uint32_t*>(ws + ft_ws_live_offset(M));
+        uint32_t* live_counts = live_count + 64;
+        unsigned long long* live_bitmap = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(live_counts) + ft_live_counts_bytes(nch));
+        uint32_t* live_list = reinterpret_cast<uint32_t*>(live_bitmap + (size_t)nch * (FT_LIVE_CHUNK / 64));
+        hipLaunchKernelGGL(k_ft_live_count, dim3(nch), dim3(FT_LIVE_CHUNK), 0, (hipStream_t)stream, grad_sigmas, grad_rgbs, M, live_counts, live_bitmap,
+                           (live_only && ft_live_only.load(std::memory_order_relaxed)) ? 0u : 1u);
+        hipLaunchKernelGGL(k_ft_live_write, dim3(nch), dim3(FT_LIVE_CHUNK), 0, (hipStream_t)stream, live_counts, live_bitmap, nch, live_list, live_count);
+        NGP_CHECK_LAUNCH("field_train_backward (live samples)");
         hipLaunchKernelGGL(k_field_train_backward<0>, dim3(blocks), dim3(RF_BLOCK), FT_LDS, (hipStream_t)stream, P, (const uint32_t*)saved, dirs, M,
-                           grad_sigmas, grad_rgbs, grad_outs, (_Float16*)grad_enc, (float*)workspace);
+                           grad_sigmas, grad_rgbs, grad_outs, (_Float16*)grad_enc, (float*)workspace, live_count, live_list);
         NGP_CHECK_LAUNCH("field_train_backward (colour net)");
         hipLaunchKernelGGL(k_field_train_backward<1>, dim3(blocks), dim3(RF_BLOCK), FT_LDS, (hipStream_t)stream, P, (const uint32_t*)saved, dirs, M,
-                           grad_sigmas, grad_rgbs, grad_outs, (_Float16*)grad_enc, (float*)workspace);
+                           grad_sigmas, grad_rgbs, grad_outs, (_Float16*)grad_enc, (float*)workspace, live_count, live_list);
         NGP_CHECK_LAUNCH("field_train_backward (density net)");
     }
     static_assert(FT_WS_FLOATS % FT_FIN_COLS == 0, "finish: whole column groups");

@@ -752,8 +752,18 @@ static gs_ws gs_layout(uint32_t B, uint32_t L) {
 __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
                                                  uint32_t* __restrict__ g_vals, uint16_t* __restrict__ g_rows, uint16_t* __restrict__ g_dir,
                                                  uint32_t B, uint32_t first, uint32_t count, uint32_t nchunks, ge_levels lv, uint32_t gridtype,
-                                                 bool align_corners, uint32_t* __restrict__ ticket) {
+                                                 bool align_corners, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ list,
+                                                 const uint32_t* __restrict__ list_count) {
     if (ticket && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *ticket = 0u;       // for the k_gs_accumulate that follows on the stream (saves a memset launch)
+    // listed samples (the field's training backward: only the samples that got a gradient): gradient row i belongs to the sample at inputs[list[i]], i < *list_count
+    if (list_count) {
+        const uint32_t n = *list_count;
+        count = n > first ? (n - first < count ? n - first : count) : 0u;
+        if (blockIdx.x * GS_CHUNK >= count) {              // nothing listed for this workgroup: an empty region
+            if (threadIdx.x <= GS_MAX_SLICES) g_dir[((size_t)blockIdx.y * (GS_MAX_SLICES + 1) + threadIdx.x) * nchunks + blockIdx.x] = 0;
+            return;
+        }
+    }
     __shared__ uint32_t s_vals[GS_REGION];             // 32 KiB: the region, slice-sorted
     __shared__ uint16_t s_rows[GS_REGION];             // 16 KiB
     __shared__ uint32_t s_hist[GS_MAX_SLICES + 1];     // entries per slice, then (after the scan) first entry of each slice
@@ -762,7 +772,8 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
     const uint32_t tid = threadIdx.x, chunk = blockIdx.x, level = blockIdx.y;
     const uint32_t i = chunk * GS_CHUNK + tid;         // sample inside this pass
     bool valid = i < count;
-    const uint32_t b = first + (valid ? i : 0u);
+    const uint32_t b = first + (valid ? i : 0u);           // the gradient's row
+    const uint32_t bx = list ? list[b] : b;                // the sample's position
     const uint32_t level_rows = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t shift = gs_shift(level_rows);
     const float scale = lv.scale[level];
@@ -773,7 +784,7 @@ __global__ __launch_bounds__(1024) void k_gs_bin(const _Float16* __restrict__ gr
     uint32_t pg[D];
     #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        const float x = inputs[(uint64_t)b * D + d];
+        const float x = inputs[(uint64_t)bx * D + d];
         if (x < 0 || x > 1) valid = false;             // out of range: contributes nothing (gridencoder.cu:251-258)
         pos[d] = x * scale + (align_corners ? 0.0f : 0.5f);
         pg[d] = (uint32_t)floorf(pos[d]);
@@ -985,7 +996,9 @@ extern "C" size_t ngp_grid_scatter_binned_workspace(uint32_t B, uint32_t L) {
 
 static int gs_run(const char* who, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t L, float S, uint32_t H,
                   uint32_t max_level_rows, uint32_t gridtype, int align_corners, int out_dtype, float out_scale, bool do_bin, bool do_sum, uint32_t level_lo,
-                  uint32_t level_hi, void* workspace, size_t workspace_bytes, void* stream) {
+                  uint32_t level_hi, const uint32_t* list, const uint32_t* list_count, void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE((list == nullptr) == (list_count == nullptr), "%s: a sample list needs its count (and the other way round)", who);
+    NGP_REQUIRE(!list || B <= GS_PASS_SAMPLES, "%s: a listed scatter takes one pass (B <= 2^22 samples)", who);
     NGP_REQUIRE(offsets && (!do_sum || grad_embeddings) && (B == 0 || !do_bin || (grad && inputs)), "%s: null pointer", who);
     NGP_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, "%s: L must be in 1..32", who);
     NGP_REQUIRE(level_lo < level_hi && level_hi <= L, "%s: bad level range", who);
@@ -1034,7 +1047,7 @@ static int gs_run(const char* who, const void* grad, const float* inputs, const 
         if (do_bin && nchunks)
             hipLaunchKernelGGL(k_gs_bin, dim3(nchunks, L), dim3(GS_CHUNK), 0, s, (const _Float16*)grad, inputs, offsets, (uint32_t*)(base + w.vals),
                                (uint16_t*)(base + w.rows), (uint16_t*)(base + w.dir), B, first, count, nchunks, lv, gridtype, align_corners != 0,
-                               do_sum ? (uint32_t*)(base + w.ticket) : (uint32_t*)nullptr);
+                               do_sum ? (uint32_t*)(base + w.ticket) : (uint32_t*)nullptr, list, list_count);
         if (do_sum) {
             // the ticket starts at zero: the bin launch just before wrote it, otherwise (no bin launch in this call) a memset does
             if (!(do_bin && nchunks) && hipMemsetAsync(base + w.ticket, 0, 4, s) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "%s: memset failed", who);
@@ -1058,7 +1071,19 @@ extern "C" int ngp_grid_scatter_binned(const void* grad, const float* inputs, co
                                        uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
                                        int out_dtype, float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
     return gs_run("grid_scatter_binned", grad, inputs, offsets, grad_embeddings, B, L, S, H, max_level_rows, gridtype, align_corners, out_dtype, out_scale,
-                  true, true, 0, L, workspace, workspace_bytes, stream);
+                  true, true, 0, L, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The same for a LISTED batch: gradient row i (of every level, rows B apart as above) belongs to the sample at inputs[list[i]], i < *list_count <= B; both on the
+// device, read by the kernels (the host never learns the count: no synchronisation).  The field's native training backward hands over the samples that got a
+// gradient this way (ngp_field_train_live_list): the rest of the batch -- half of it on a converged scene -- is neither binned nor read.  B <= 2^22.
+extern "C" int ngp_grid_scatter_binned_listed(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                              uint32_t B, uint32_t L, float S, uint32_t H, uint32_t max_level_rows, uint32_t gridtype, int align_corners,
+                                              int out_dtype, float out_scale, const uint32_t* list, const uint32_t* list_count,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(list && list_count, "grid_scatter_binned_listed: null list");
+    return gs_run("grid_scatter_binned_listed", grad, inputs, offsets, grad_embeddings, B, L, S, H, max_level_rows, gridtype, align_corners, out_dtype, out_scale,
+                  true, true, 0, L, list, list_count, workspace, workspace_bytes, stream);
 }
 
 // The same in two steps, for a caller that wants the table one GROUP OF LEVELS at a time (the data-parallel gradient exchange starts the all-reduce
@@ -1070,5 +1095,16 @@ extern "C" int ngp_grid_scatter_binned_phase(int phase, const void* grad, const 
                                              void* stream) {
     NGP_REQUIRE(phase == 1 || phase == 2, "grid_scatter_binned_phase: phase must be 1 (bin) or 2 (sum a group of levels)");
     return gs_run("grid_scatter_binned_phase", grad, inputs, offsets, grad_embeddings, B, L, S, H, max_level_rows, gridtype, align_corners, out_dtype, out_scale,
-                  phase == 1, phase == 2, phase == 1 ? 0u : level_lo, phase == 1 ? L : level_hi, workspace, workspace_bytes, stream);
+                  phase == 1, phase == 2, phase == 1 ? 0u : level_lo, phase == 1 ? L : level_hi, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ... and for a listed batch (list, list_count as in ngp_grid_scatter_binned_listed; phase 2 does not read them)
+extern "C" int ngp_grid_scatter_binned_phase_listed(int phase, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                                    uint32_t B, uint32_t L, uint32_t level_lo, uint32_t level_hi, float S, uint32_t H, uint32_t max_level_rows,
+                                                    uint32_t gridtype, int align_corners, int out_dtype, float out_scale, const uint32_t* list,
+                                                    const uint32_t* list_count, void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(phase == 1 || phase == 2, "grid_scatter_binned_phase_listed: phase must be 1 (bin) or 2 (sum a group of levels)");
+    NGP_REQUIRE(list && list_count, "grid_scatter_binned_phase_listed: null list");
+    return gs_run("grid_scatter_binned_phase_listed", grad, inputs, offsets, grad_embeddings, B, L, S, H, max_level_rows, gridtype, align_corners, out_dtype, out_scale,
+                  phase == 1, phase == 2, phase == 1 ? 0u : level_lo, phase == 1 ? L : level_hi, list, list_count, workspace, workspace_bytes, stream);
 }

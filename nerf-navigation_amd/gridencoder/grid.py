@@ -111,9 +111,12 @@ def level_group_rows(offsets, L, groups):
     return [(cuts[g], cuts[g + 1], int(bounds[cuts[g]]), int(bounds[cuts[g + 1]])) for g in range(groups - 1, -1, -1)]
 
 
-def table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, align_corners, out_dtype=torch.float32, out_scale=1.0, on_group=None, groups=None):
+def table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, align_corners, out_dtype=torch.float32, out_scale=1.0, on_group=None, groups=None,
+                          listed=None):
     """grad [L,B,2] half (level-major), inputs [B,3] float32 in [0,1] -> the table gradient [sO,2] in `out_dtype`, summed on chip
     (ngp_grid_scatter_binned).  Shared by _grid_encode.backward and the field's native training step (ngp/field.py).
+    listed = (list, count) device addresses: gradient row i belongs to the sample at inputs[list[i]], i < *count (the field's backward lists the samples
+    that got a gradient, ngp_field_train_live_list); B <= PHASE_MAX_POINTS.
     on_group(out, row_lo, row_hi): called after the rows [row_lo, row_hi) of `out` (a group of levels, finest levels first, the few rows of the
     coarsest levels last) have been queued -- the data-parallel gradient exchange starts their all-reduce while the next group is summed.
     The SEQUENCE of on_group calls (row ranges, order) depends on (offsets, L, groups) only, never on B: B is a rank's own sample count, and ranks whose
@@ -124,20 +127,23 @@ def table_gradient_binned(grad, inputs, offsets, B, L, S, H, gridtype, align_cor
     out = torch.empty(n, 2, dtype=out_dtype, device=inputs.device)
     ws = _hip.workspace(lib.ngp_grid_scatter_binned_workspace(B, L), inputs.device)
     pieces = level_group_rows(offsets, L, LEVEL_GROUPS if groups is None else groups) if on_group is not None else None
+    if listed is not None and not 0 < B <= PHASE_MAX_POINTS:
+        raise ValueError("a listed scatter takes between 1 and 2^22 samples")
+    who = (listed,) if listed is not None else ()              # the listed entry points take (list, count) in front of the workspace
+    phase_fn = lib.ngp_grid_scatter_binned_phase_listed if listed is not None else lib.ngp_grid_scatter_binned_phase
+    whole_fn = lib.ngp_grid_scatter_binned_listed if listed is not None else lib.ngp_grid_scatter_binned
+    tail = (float(S), H, rows, gridtype, int(align_corners), _hip.dtype_code(out_dtype), float(out_scale), *(who[0] if who else ()), _hip.ptr(ws), ws.numel(),
+            _hip.stream())
     if pieces is not None and len(pieces) > 1 and 0 < B <= PHASE_MAX_POINTS:
         args = (B, L)
-        tail = (float(S), H, rows, gridtype, int(align_corners), _hip.dtype_code(out_dtype), float(out_scale), _hip.ptr(ws), ws.numel(), _hip.stream())
         with _hip.timed("grid_encode_backward"):
-            _hip.check(lib.ngp_grid_scatter_binned_phase(1, _hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), *args, 0, L, *tail), "grid_scatter_binned_phase")
+            _hip.check(phase_fn(1, _hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), *args, 0, L, *tail), "grid_scatter_binned_phase")
             for lo, hi, row_lo, row_hi in pieces:
-                _hip.check(lib.ngp_grid_scatter_binned_phase(2, _hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), *args, lo, hi, *tail),
-                           "grid_scatter_binned_phase")
+                _hip.check(phase_fn(2, _hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), *args, lo, hi, *tail), "grid_scatter_binned_phase")
                 on_group(out, row_lo, row_hi)
         return out
     with _hip.timed("grid_encode_backward"):
-        _hip.check(lib.ngp_grid_scatter_binned(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), B, L, float(S), H, rows, gridtype,
-                                               int(align_corners), _hip.dtype_code(out_dtype), float(out_scale), _hip.ptr(ws), ws.numel(), _hip.stream()),
-                   "grid_scatter_binned")
+        _hip.check(whole_fn(_hip.ptr(grad), _hip.ptr(inputs), _hip.ptr(offsets), _hip.ptr(out), B, L, *tail), "grid_scatter_binned")
     for lo, hi, row_lo, row_hi in pieces or ():
         on_group(out, row_lo, row_hi)
     return out

@@ -94,11 +94,21 @@ class _field_train(Function):
         grad_enc = torch.empty(enc.num_levels, M, enc.level_dim, dtype=torch.float16, device=x.device)
         g_ws = torch.empty(ws_half.numel(), dtype=torch.float32, device=x.device)
         g_wc = torch.empty(wc_half.numel(), dtype=torch.float32, device=x.device)
-        work = _hip.workspace(L.ngp_field_train_workspace(M), x.device)      # per-workgroup partial sums of the weight gradients: nothing to clear
+        work = _hip.workspace(L.ngp_field_train_workspace(M), x.device)      # per-workgroup partial sums of the weight gradients, the live list: nothing to clear
+        from gridencoder import grid as G
+        binned = bool(ctx.needs_input_grad[2]) and G.BINNED_SCATTER and G.offsets_max_rows(enc.offsets) <= (1 << 19)
+        # only the samples that got a gradient (behind the compositor's early exit half of a converged batch gets none): the kernels list them and the
+        # binned scatter takes the list along; the atomic scatter (tables beyond 2^19 rows per level) wants every row, in sample order
+        live_only = binned and 0 < M <= G.PHASE_MAX_POINTS
         with _hip.timed("field_train_backward"):
             _hip.check(L.ngp_field_train_backward(ctypes.byref(ctx.fstruct), _hip.ptr(saved), _hip.ptr(d), M, _hip.ptr(g_sig), _hip.ptr(g_rgb),
-                                                  _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), _hip.stream()),
-                       "field_train_backward")
+                                                  _hip.ptr(grad_enc), _hip.ptr(g_ws), _hip.ptr(g_wc), _hip.ptr(work), work.numel(), int(live_only),
+                                                  _hip.stream()), "field_train_backward")
+        listed = None
+        if live_only:
+            p_list, p_count = ctypes.c_void_p(), ctypes.c_void_p()
+            _hip.check(L.ngp_field_train_live_list(_hip.ptr(work), M, ctypes.byref(p_list), ctypes.byref(p_count)), "field_train_live_list")
+            listed = (p_list, p_count)
         # data-parallel training: the exchange (ngp/train.py GradExchange) takes the gradients as they appear -- the weight bucket now, so that its
         # all-reduce runs underneath the table scatter; the table gradient as the half tensor the scatter writes, pre-divided by the world size
         sink = getattr(field, "grad_sink", None)
@@ -107,17 +117,16 @@ class _field_train(Function):
             sink.deliver([field.sigma_net.weights, field.color_net.weights], torch.cat([g_ws, g_wc]).mul_(inv))
         grad_emb = None
         if ctx.needs_input_grad[2]:
-            from gridencoder import grid as G
             inputs = ((x + field.bound) / (2 * field.bound)).contiguous()          # GridEncoder.forward (gridencoder/grid.py:144)
             S = float(np.log2(enc.per_level_scale))
-            if G.BINNED_SCATTER and G.offsets_max_rows(enc.offsets) <= (1 << 19):
+            if binned:
                 # summed on chip (exactly, 64-bit fixed point) and written once: as the float32 gradient of the float32 parameter (no zero fill, no
                 # atomics, no widening), or, for the exchange, as a half tensor scaled by 1 / world size (half the bytes on the links)
                 grad_emb = G.table_gradient_binned(grad_enc, inputs, enc.offsets, M, enc.num_levels, S, enc.base_resolution, enc.gridtype_id,
                                                    enc.align_corners, out_dtype=torch.float16 if sink is not None else torch.float32,
                                                    out_scale=(1.0 / sink.world_size()) if sink is not None else 1.0,
                                                    on_group=(lambda out, r0, r1: sink.deliver_rows(enc.embeddings, out, r0, r1)) if sink is not None else None,
-                                                   groups=getattr(sink, "level_groups", None))
+                                                   groups=getattr(sink, "level_groups", None), listed=listed)
                 delivered_table = sink is not None       # group by group, finest levels first: their all-reduce runs while the coarser ones are summed
             else:
                 grad_emb = torch.zeros_like(emb_half)

@@ -61,6 +61,9 @@ _SIGNATURES = {
     "ngp_grid_scatter_binned_workspace": (c_sz, [c_u32, c_u32]),
     "ngp_grid_scatter_binned": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_u32, c_u32, c_u32, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
     "ngp_grid_scatter_binned_phase": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_u32, c_u32, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
+    "ngp_grid_scatter_binned_listed": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_u32, c_u32, c_u32, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_grid_scatter_binned_phase_listed": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_u32, c_u32, c_int, c_int, c_f32, c_vp, c_vp,
+                                                     c_vp, c_sz, c_vp]),
     "ngp_adam_step": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp]),
     "ngp_train_mix_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_train_mix_backward": (c_int, [c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp]),
@@ -86,10 +89,12 @@ _SIGNATURES = {
     "ngp_field_train_saved_bytes": (c_sz, [c_u32]),
     "ngp_field_train_workspace": (c_sz, [c_u32]),
     "ngp_field_train_forward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "ngp_field_train_backward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_field_train_backward": (c_int, [c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "ngp_field_train_live_list": (c_int, [c_vp, c_u32, c_vp, c_vp]),
     "ngp_render_frame_workspace": (c_sz, [c_u32]),
     "ngp_render_set_block_skip": (c_int, [c_int]),
     "ngp_field_train_set_two_pass": (c_int, [c_int]),
+    "ngp_field_train_set_live_only": (c_int, [c_int]),
     "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_grid_encode_backward_inputs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_vp, c_u32, c_int, c_int, c_vp]),
@@ -211,6 +216,8 @@ def lib():
         _lib = _GuardedLib(handle)
         if os.environ.get("NGP_FT_TWO_PASS") in ("0", "1"):              # A/B switch of the training forward (tools, bench.py --mode train); default: two passes
             handle.ngp_field_train_set_two_pass(int(os.environ["NGP_FT_TWO_PASS"]))
+        if os.environ.get("NGP_FT_LIVE_ONLY") in ("0", "1"):             # ... of the training backward (live samples only | all samples)
+            handle.ngp_field_train_set_live_only(int(os.environ["NGP_FT_LIVE_ONLY"]))
     return _lib
 
 
