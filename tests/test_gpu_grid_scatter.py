@@ -157,3 +157,32 @@ def test_binned_scatter_full_size_checksum_and_reproducibility(oracle, dev):
     twice = G.table_gradient_binned((tg * 2).contiguous(), tx, to, B, L, np.log2(pls), 16, 0, False)
     # scaling by 2 commutes with every rounding in the path except where a product falls into the half subnormals (absolute spacing 2^-24)
     assert float((twice - out * 2).abs().max()) <= 1e-4 * float(out.abs().max())
+
+
+@pytest.mark.parametrize("count", [0, 1, 1023, 1024, 20000, 70001])
+def test_listed_scatter_equals_the_scatter_of_the_listed_samples(oracle, dev, count):
+    """ngp_grid_scatter_binned_listed: gradient row i belongs to the sample at inputs[list[i]], i < *count (both on the device; the field's training
+    backward lists the samples that got a gradient).  Scattering the first `count` list entries must give the table the unlisted entry point gives for
+    those samples gathered by hand -- exactly when the list keeps neighbours together (the run sums are then the same), and rows from `count` on are
+    neither read (they hold NaN here) nor binned; count = 0 writes a table of zeros."""
+    import ctypes
+    from gridencoder import grid as G
+    B, L = 70001, 16
+    offsets, pls = oracle.grid_offsets(3, L, 2, 2, 16, 19, 4096, False)
+    x = ray_points(B // 50 + 1, 50, 5)[:B]
+    rng = np.random.default_rng(6)
+    order = np.sort(rng.choice(B, size=B, replace=False)[:max(count, 1)]).astype(np.int32)      # an increasing list, like the ordered compaction's
+    order = np.concatenate([order, np.zeros(B - len(order), np.int32)])
+    grad = (rng.normal(size=(L, B, 2)) * 0.1).astype(np.float16)
+    grad[:, count:] = np.nan
+    lst, cnt = t(order, dev), torch.tensor([count], dtype=torch.int32, device=dev)
+    listed = (ctypes.c_void_p(lst.data_ptr()), ctypes.c_void_p(cnt.data_ptr()))
+    got = G.table_gradient_binned(t(grad, dev), t(x, dev), t(offsets, dev), B, L, np.log2(pls), 16, 0, False, listed=listed)
+    assert bool(torch.isfinite(got).all())
+    if count == 0:
+        assert not bool(got.any())
+        return
+    sub_x = np.ascontiguousarray(x[order[:count]])
+    sub_g = np.ascontiguousarray(grad[:, :count])
+    want = G.table_gradient_binned(t(sub_g, dev), t(sub_x, dev), t(offsets, dev), count, L, np.log2(pls), 16, 0, False)
+    assert torch.equal(got, want)
