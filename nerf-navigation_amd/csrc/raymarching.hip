@@ -447,6 +447,45 @@ __global__ __launch_bounds__(RM_BLOCK) void k_march_train_scan(uint32_t* __restr
     }
 }
 
+// The three launches above (per-64-ray sums, their scan, the rays' offsets) as ONE single-workgroup launch, for the wave-per-ray count pass on a
+// training-sized batch (a 4,096-ray step: 4 rounds of 1,024 rays; 19 us of launches -> one of ~6): the same slots, offsets, counters and bases.
+static constexpr uint32_t RM_OFFSETS_BLOCK = 1024, RM_OFFSETS_MAX_RAYS = 1u << 16;
+__global__ __launch_bounds__(RM_OFFSETS_BLOCK) void k_march_train_offsets(int* __restrict__ rays, int* __restrict__ counter, uint32_t N, uint32_t M,
+                                                                      uint32_t* __restrict__ bases) {
+    __shared__ uint32_t lds4[RM_OFFSETS_BLOCK / 64];
+    __shared__ uint32_t carry, s_dropped;
+    const uint32_t start = (uint32_t)counter[0], ray_base = (uint32_t)counter[1];
+    if (threadIdx.x == 0) { carry = start; s_dropped = 0xFFFFFFFFu; }
+    __syncthreads();
+    uint32_t dropped = 0xFFFFFFFFu;                   // point index of the first ray whose samples do not fit (at most one ray qualifies)
+    for (uint32_t n0 = 0; n0 < N; n0 += RM_OFFSETS_BLOCK) {
+        const uint32_t n = n0 + threadIdx.x, slot = ray_base + n;
+        const bool live = n < N && slot < N;
+        const uint32_t num_steps = live ? (uint32_t)rays[3ull * slot + 2] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_inclusive_scan<RM_OFFSETS_BLOCK / 64>(num_steps, lds4, total);
+        const uint32_t c = carry;
+        if (live) {
+            const uint32_t point_index = c + inc - num_steps;
+            rays[3ull * slot] = (int)n;
+            rays[3ull * slot + 1] = (int)point_index;
+            if (num_steps != 0 && point_index < M && point_index + num_steps >= M) dropped = point_index;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (dropped != 0xFFFFFFFFu) s_dropped = dropped;  // (one thread at most)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bases[0] = start;
+        bases[1] = ray_base;
+        bases[2] = s_dropped != 0xFFFFFFFFu ? s_dropped : carry;      // every ray fits: the unfilled tail starts behind the last one
+        counter[0] = (int)carry;
+        counter[1] = (int)(ray_base + N);
+    }
+}
+
 // The slots no ray of the call fills, zeroed like the torch.zeros buffers the reference's wrapper hands in (raymarching.py:205-208; a zero delta marks
 // a sample that does not exist, raymarching.cu:548): the tail [bases[2], M) -- ray slots are prefix sums, so from the first ray that does not fit on
 // nothing is written -- and the head [0, bases[0]) below the point base the caller's counter[0] held at entry (0 for every caller in this repository;
@@ -593,14 +632,19 @@ static int rm_march_rays_train(const float* rays_o, const float* rays_d, const u
     // one wave per ray when the lattice is closed-form (constant step) and the sample parameters can be recorded; else one lane per ray
     const int wave_mode = rm_wave_march_enabled.load(std::memory_order_relaxed);
     const bool wave_per_ray = tbuf && cbytes && dt_gamma == 0.0f && C <= 4 && wave_mode != 0;
-    if (wave_per_ray) {
+    if (wave_per_ray && N <= RM_OFFSETS_MAX_RAYS) {
         hipLaunchKernelGGL(k_march_train_count_wave, dim3(N), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, tbuf, wave_mode == 2 ? 1u : 0u);
-        hipLaunchKernelGGL(k_march_train_sum64, dim3(ngp_div_up(nblocks, RM_BLOCK)), dim3(RM_BLOCK), 0, s, rays, counter, N, nblocks, block_sums);
+        hipLaunchKernelGGL(k_march_train_offsets, dim3(1), dim3(RM_OFFSETS_BLOCK), 0, s, rays, counter, N, M, bases);
     } else {
-        hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, block_sums, tbuf);
+        if (wave_per_ray) {
+            hipLaunchKernelGGL(k_march_train_count_wave, dim3(N), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, tbuf, wave_mode == 2 ? 1u : 0u);
+            hipLaunchKernelGGL(k_march_train_sum64, dim3(ngp_div_up(nblocks, RM_BLOCK)), dim3(RM_BLOCK), 0, s, rays, counter, N, nblocks, block_sums);
+        } else {
+            hipLaunchKernelGGL(k_march_train_count, dim3(nblocks), dim3(RM_RAY_BLOCK), cbytes, s, a, rays, counter, block_sums, tbuf);
+        }
+        hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
+        hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas, tbuf ? 1 : 0);
     }
-    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(RM_BLOCK), 0, s, block_sums, nblocks, counter, N, bases);
-    hipLaunchKernelGGL(k_march_train_write, dim3(nblocks), dim3(RM_RAY_BLOCK), 0, s, a, rays, block_sums, bases, xyzs, dirs, deltas, tbuf ? 1 : 0);
     if (tbuf) hipLaunchKernelGGL(k_march_train_fill, dim3(N), dim3(RM_RAY_BLOCK), 0, s, a, rays, bases, tbuf, xyzs, dirs, deltas);
     if (zero_tail && M) {
         const uint32_t zb = ngp_div_up(3ull * M, RM_BLOCK * 8ull);
