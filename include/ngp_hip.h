@@ -133,6 +133,9 @@ int ngp_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_a
 int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
                        const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
                        void* stream);
+/* the same with rgbs as halves (a field under autocast returns halves; the reference's wrapper widens them first, raymarching.py:343): same values */
+int ngp_composite_rays_half(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                            const void* rgbs_half, const float* deltas, float* weights_sum, float* depth, float* image, void* stream);
 
 /* Not in the reference's native surface: stable compaction of rays_alive (the reference does it with a torch
  * boolean mask, nerf/renderer.py:365).  out [n_alive] i32, n_out [1] i32 device counter (overwritten).

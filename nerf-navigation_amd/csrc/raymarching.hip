@@ -1148,9 +1148,12 @@ __global__ __launch_bounds__(BLOCK) void k_march_rays(uint32_t n_alive, uint32_t
     }
 }
 
+// RGB_T: float (the reference's kernel) or _Float16 -- the colours of a field under autocast, which the reference's wrapper widens to float32 first
+// (raymarching.py:343 custom_fwd(cast_inputs=float32): an elementwise launch per iteration of the inference loop); widening in the load is the same value
+template <class RGB_T>
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_rays(uint32_t n_alive, uint32_t n_step, int* __restrict__ rays_alive,
                                                              float* __restrict__ rays_t, const float* __restrict__ sigmas,
-                                                             const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                             const RGB_T* __restrict__ rgbs, const float* __restrict__ deltas,
                                                              float* __restrict__ weights_sum, float* __restrict__ depth,
                                                              float* __restrict__ image) {
     // reference: raymarching.cu:829-913
@@ -1158,7 +1161,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_rays(uint32_t n_aliv
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     const float* s = sigmas + (uint64_t)n * n_step;
-    const float* c = rgbs + 3ull * n * n_step;
+    const RGB_T* c = rgbs + 3ull * n * n_step;
     const float* dl = deltas + 2ull * n * n_step;
     float t = rays_t[index];
     float ws = weights_sum[index], d = depth[index];
@@ -1172,7 +1175,7 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_composite_rays(uint32_t n_aliv
         ws += w;
         t += dl[1];
         d += w * t;
-        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        r += w * (float)c[0]; g += w * (float)c[1]; b += w * (float)c[2];
         if ((double)T < 1e-4) break;                  // double literal in the reference (:890)
         s++; c += 3; dl += 2; step++;
     }
@@ -1231,10 +1234,20 @@ extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* ra
                                   const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
     if (n_alive == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "composite_rays: null pointer");
-    if (n_alive == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_rays, dim3(ngp_div_up(n_alive, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_composite_rays<float>, dim3(ngp_div_up(n_alive, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
                        n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
     NGP_CHECK_LAUNCH("composite_rays");
+    return NGP_OK;
+}
+
+// rgbs as halves [n_alive * n_step, 3] (what a field under autocast returns): the same values without the widening copy
+extern "C" int ngp_composite_rays_half(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                                       const void* rgbs_half, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
+    if (n_alive == 0) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs_half && deltas && weights_sum && depth && image, "composite_rays_half: null pointer");
+    hipLaunchKernelGGL(k_composite_rays<_Float16>, dim3(ngp_div_up(n_alive, RM_RAY_BLOCK)), dim3(RM_RAY_BLOCK), 0, (hipStream_t)stream,
+                       n_alive, n_step, rays_alive, rays_t, sigmas, (const _Float16*)rgbs_half, deltas, weights_sum, depth, image);
+    NGP_CHECK_LAUNCH("composite_rays_half");
     return NGP_OK;
 }
 

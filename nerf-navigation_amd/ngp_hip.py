@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ngp_march_rays_fill": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
                                     c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_sz, c_vp]),
     "ngp_composite_rays": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ngp_composite_rays_half": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ngp_compact_alive_workspace": (c_sz, [c_u32]),
     "ngp_compact_alive": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "ngp_density_grid_points": (c_u32, [c_u32, c_u32, c_int]),

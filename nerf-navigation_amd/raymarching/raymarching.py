@@ -268,12 +268,17 @@ class _composite_rays(Function):
     """reference: raymarching/raymarching.py:340-359 (returns an empty tuple; mutates its arguments in place)"""
 
     @staticmethod
-    @_f32_forward
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
-        _hip.check(_hip.lib().ngp_composite_rays(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t),
-                                                 _hip.ptr(sigmas.contiguous()), _hip.ptr(rgbs.contiguous()), _hip.ptr(deltas),
-                                                 _hip.ptr(weights_sum), _hip.ptr(depth), _hip.ptr(image), _hip.stream()),
-                   "composite_rays")
+        # (custom_fwd(cast_inputs=float32) in the reference: under autocast half arguments are widened.  Half COLOURS -- what a field under autocast
+        #  returns -- are widened by the kernel's own loads instead: the same values, one elementwise launch per iteration of the inference loop less)
+        half_rgb = rgbs.dtype == torch.float16 and rgbs.is_cuda
+        if torch.is_autocast_enabled("cuda"):
+            sigmas, deltas = (a.float() if a.dtype in (torch.float16, torch.bfloat16) else a for a in (sigmas, deltas))
+            if not half_rgb and rgbs.dtype in (torch.float16, torch.bfloat16):
+                rgbs = rgbs.float()
+        fn = _hip.lib().ngp_composite_rays_half if half_rgb else _hip.lib().ngp_composite_rays
+        _hip.check(fn(n_alive, n_step, _hip.ptr(rays_alive), _hip.ptr(rays_t), _hip.ptr(sigmas.contiguous()), _hip.ptr(rgbs.contiguous()), _hip.ptr(deltas),
+                      _hip.ptr(weights_sum), _hip.ptr(depth), _hip.ptr(image), _hip.stream()), "composite_rays")
         return tuple()
 
 

@@ -171,6 +171,29 @@ def test_march_then_composite_loop_bit_exact(oracle, dev, scene):
     assert ws_r.max() > 0.9, "some rays must saturate (exercises the T < 1e-4 exit)"
 
 
+def test_composite_rays_takes_half_colours_as_the_widened_ones(oracle, dev, scene):
+    """a field under autocast returns half colours; the reference's wrapper widens them to float32 (custom_fwd cast_inputs) before its kernel reads them,
+    ngp_composite_rays_half widens in the load: the same accumulators and alive list, bit for bit"""
+    import raymarching
+    o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
+    N = 3000
+    alive = np.arange(N, dtype=np.int32)
+    x, _, l = oracle.march_rays(N, 4, alive, nears.copy(), o, d, BOUND, bf, CAS, H, nears, fars, 128, False, 0.0, 1024)
+    rng = np.random.default_rng(1)
+    sig = (40.0 * np.exp(-4.0 * (x ** 2).sum(1))).astype(np.float32)
+    rgb_h = rng.uniform(0, 1, size=(x.shape[0], 3)).astype(np.float16)
+    out = []
+    for colours in (t(rgb_h, dev), t(rgb_h.astype(np.float32), dev)):
+        a, rt = t(alive, dev), t(nears.copy(), dev)
+        ws, dp, im = (torch.zeros(o.shape[0], device=dev), torch.zeros(o.shape[0], device=dev), torch.zeros(o.shape[0], 3, device=dev))
+        with torch.autocast("cuda", dtype=torch.float16):
+            raymarching.composite_rays(N, 4, a, rt, t(sig, dev), colours, t(l, dev), ws, dp, im)
+        out.append((a, rt, ws, dp, im))
+    for u, v in zip(*out):
+        assert torch.equal(u, v)
+    assert float(out[0][2].max()) > 0.5 and int((out[0][0] < 0).sum()) > 0
+
+
 @pytest.mark.parametrize("perturb", [False, True])
 @pytest.mark.parametrize("mode", ["first_epoch", "mean_count", "force_all"])
 def test_march_rays_train_bit_exact(oracle, dev, scene, perturb, mode):
