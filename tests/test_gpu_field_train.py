@@ -95,6 +95,25 @@ def test_fused_training_step_with_samples_that_get_no_gradient(dev, M):
         assert float((a - b).abs().mean()) <= 1e-3 * float(b.abs().mean()) + 1e-9, name
 
 
+@pytest.mark.parametrize("M", [1, 63, 4096, 70001])
+def test_fused_training_step_when_no_sample_gets_a_gradient(dev, M):
+    """an empty live list (every incoming gradient +0, e.g. a batch of rays that hit nothing): zero gradients everywhere, written (not left as they were)"""
+    field, W = _field(dev)
+    field.train()
+    x, d, gs, gc = _points(W, M, dev, seed=M)
+    got = _step(field, True, x, d, torch.zeros_like(gs), torch.zeros_like(gc), 1.0)
+    for g in got[2:]:
+        assert bool(torch.isfinite(g).all()) and not bool(g.any())
+    # ... and ONE live sample among M: only its 16 x 8 table rows (at most) and the weights get a gradient
+    one = torch.zeros_like(gs)
+    one[M // 2] = 1.0
+    got = _step(field, True, x, d, one, torch.zeros_like(gc), 1.0)
+    ref = _step(field, False, x, d, one, torch.zeros_like(gc), 1.0)
+    assert 0 < int((got[2].abs().sum(-1) > 0).sum()) <= 128
+    for a, b in zip(got[2:4], ref[2:4]):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12
+
+
 def test_fused_training_is_used_only_where_it_applies(dev):
     field, W = _field(dev)
     x, d, gs, gc = _points(W, 256, dev, seed=1)

@@ -176,7 +176,8 @@ def test_composite_rays_takes_half_colours_as_the_widened_ones(oracle, dev, scen
     ngp_composite_rays_half widens in the load: the same accumulators and alive list, bit for bit"""
     import raymarching
     o, d, nears, fars, bf = scene["o"], scene["d"], scene["nears"], scene["fars"], scene["bitfield"]
-    N = 3000
+    N = 2000
+    assert N <= o.shape[0]
     alive = np.arange(N, dtype=np.int32)
     x, _, l = oracle.march_rays(N, 4, alive, nears.copy(), o, d, BOUND, bf, CAS, H, nears, fars, 128, False, 0.0, 1024)
     rng = np.random.default_rng(1)
@@ -191,7 +192,7 @@ def test_composite_rays_takes_half_colours_as_the_widened_ones(oracle, dev, scen
         out.append((a, rt, ws, dp, im))
     for u, v in zip(*out):
         assert torch.equal(u, v)
-    assert float(out[0][2].max()) > 0.5 and int((out[0][0] < 0).sum()) > 0
+    assert float(out[0][2].max()) > 0.2 and int((out[0][0] < 0).sum()) > 0          # four samples per ray: some weight, and rays that ran out of samples
 
 
 @pytest.mark.parametrize("perturb", [False, True])
