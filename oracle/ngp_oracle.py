@@ -217,6 +217,10 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfi
                align=-1, perturb=False, dt_gamma=0.0, max_steps=1024):
     """raymarching/raymarching.py:292-337 (M padded past the next multiple of align)."""
     rays_o, rays_d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    # the C restatement indexes like the reference's kernel, unchecked: a ray index past the arrays reads garbage and can march for ever
+    alive = np.asarray(rays_alive).reshape(-1)[:n_alive]
+    if alive.size < n_alive or (n_alive and (int(alive.max()) >= rays_o.shape[0] or int(alive.max()) >= np.asarray(rays_t).size)):
+        raise ValueError("march_rays: rays_alive names rays the inputs do not hold")
     M = n_alive * n_step
     if align > 0:
         M += align - (M % align)
