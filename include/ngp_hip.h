@@ -91,8 +91,9 @@ int ngp_march_rays_train_filled(const float* rays_o, const float* rays_d, const 
                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* Validation switch, process-wide, default 1: with dt_gamma == 0 the count pass of ngp_march_rays_train marches one WAVE per ray (64 lattice
- * points per step, csrc/raymarching.hip: k_march_train_count_wave) instead of one lane per ray.  Same samples, counts and order either way;
- * returns the previous setting. */
+ * points per step, csrc/raymarching.hip: k_march_train_count_wave) instead of one lane per ray (0).  1: a window's control flow is accepted by one
+ * ballot when the cheap guess holds; 2: every window goes through the run-by-run replay that 1 falls back to.  Same samples, counts and order in
+ * every mode; returns the previous setting. */
 int ngp_march_set_wave_per_ray(int enabled);   /* also selects the wave-per-ray kernels of ngp_composite_rays_train_* */
 int ngp_composite_set_scan(int enabled);       /* wave-per-ray compositors: chains as lane scans (1, default) or every lane running the recurrence (0); returns the previous setting */
 
