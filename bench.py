@@ -237,8 +237,27 @@ def fit_model(args, dev, W, teacher):
     import ngp_hip
     tail = 0 if args.no_train_block else max(0, min(int(args.train_steps), args.fit_steps // 2))
     t0 = time.perf_counter()
-    for k in range(args.fit_steps - tail):
-        loss = step(k)
+    # ... and steps [32, 32 + tail) are its early phase (the occupancy grid still nearly full: ~1.8 M points per step): two more synchronisations, no more steps
+    early = None
+    head0 = 32 if tail and args.fit_steps - tail >= 32 + tail else args.fit_steps
+    if head0 == args.fit_steps:
+        for k in range(args.fit_steps - tail):
+            loss = step(k)
+    else:
+        with no_gc_pauses():                               # (entered before the untimed steps: the collector's own 36 ms must not idle the GPU just before the timed ones)
+            for k in range(head0):
+                loss = step(k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(head0, head0 + tail):
+                loss = step(k)
+            torch.cuda.synchronize()
+            early_wall = time.perf_counter() - t1
+        n = min(16, student.local_step)
+        early = {"steps": tail, "first_step": head0, "ms_per_step": 1e3 * early_wall / tail, "rays_per_s": n_rays * tail / early_wall,
+                 "points_per_step": float(student.step_counter[:n, 0].float().mean().item())}
+        for k in range(head0 + tail, args.fit_steps - tail):
+            loss = step(k)
     train = None
     if tail:
         ngp_hip.TIMERS = {}
@@ -266,7 +285,8 @@ def fit_model(args, dev, W, teacher):
                  "points_per_step": points, "host_queue_ms_per_step": 1e3 * queued / tail,
                  "forward_roofline": roof("k_ft_encode_levels + k_field_train_forward (level-by-level gather of 512 B per point, then both networks), event-timed together", timers["field_train_forward"]),
                  "scatter_roofline": roof("k_gs_bin + k_gs_accumulate (binned table-gradient scatter)", timers["grid_encode_backward"]),
-                 "field_backward_ms": timers["field_train_backward"], "optimizer_ms": timers["adam_step"]}
+                 "field_backward_ms": timers["field_train_backward"], "optimizer_ms": timers["adam_step"],
+                 "early_phase": early}
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     student.eval()
