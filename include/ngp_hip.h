@@ -144,6 +144,12 @@ int ngp_composite_rays_half(uint32_t n_alive, uint32_t n_step, int32_t* rays_ali
 size_t ngp_compact_alive_workspace(uint32_t n_alive);
 int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same, and the count also reaches the HOST without a stream synchronisation: host_pair = 2 int32 of pinned coherent memory from ngp_host_words_alloc;
+ * the kernel stores the count in host_pair[0], then `seq` in host_pair[1] (system scope, release); the caller polls host_pair[1] == seq. */
+int ngp_compact_alive_publish(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out, int32_t* host_pair, int32_t seq,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int ngp_host_words_alloc(uint32_t n_words, void** host_ptr);   /* pinned, coherent, device-visible, zeroed; 1 .. 4096 words */
+int ngp_host_words_free(void* host_ptr);
 
 /* ------------------------------------------------------------------------ */
 /* density-grid maintenance.  Reference: nerf/renderer.py:381-537 -- Python loops over torch ops      */

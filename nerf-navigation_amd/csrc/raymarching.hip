@@ -7,6 +7,7 @@
 // bitfield (cascade * 128^3 / 8 = 0.5 MB at bound 2) is L2-resident; the kernels are bound by the divergent
 // per-ray loops, not by HBM.
 #include <atomic>
+#include <cstring>
 #include "ngp_march.h"
 
 thread_local char ngp_err_buf[512] = {0};
@@ -1272,7 +1273,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_compact_count(const int* __restric
 // (<= 2,500 L2-resident words for an 800 x 800 frame, 256 lanes at a time) instead of waiting for a one-workgroup scan launch in between -- the loop
 // runs this once per iteration, ~66 times per frame, and every launch is ~5 us on its critical path.  The last workgroup also publishes the total.
 __global__ __launch_bounds__(RM_BLOCK) void k_compact_write(const int* __restrict__ rays_alive, uint32_t n_alive,
-                                                            const uint32_t* __restrict__ block_sums, int* __restrict__ out, int* __restrict__ n_out) {
+                                                            const uint32_t* __restrict__ block_sums, int* __restrict__ out, int* __restrict__ n_out,
+                                                            int* host_pair, int seq) {
     __shared__ uint32_t lds4[RM_BLOCK / 64], lds_base[RM_BLOCK / 64];
     const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
     const int v = (n < n_alive) ? rays_alive[n] : -1;
@@ -1297,6 +1299,10 @@ __global__ __launch_bounds__(RM_BLOCK) void k_compact_write(const int* __restric
         #pragma unroll
         for (uint32_t w = 0; w < RM_BLOCK / 64; w++) total += lds_base[w];
         n_out[0] = (int)(total + mine);
+        if (host_pair) {                                                   // the count straight into the caller's pinned words, then the sequence number it waits for
+            __hip_atomic_store(host_pair, (int)(total + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_pair + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1304,15 +1310,44 @@ extern "C" size_t ngp_compact_alive_workspace(uint32_t n_alive) {
     return sizeof(uint32_t) * ((size_t)ngp_div_up(n_alive ? n_alive : 1, RM_BLOCK) + 4);
 }
 
-extern "C" int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+static int rm_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out, int32_t* host_pair, int32_t seq,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     NGP_REQUIRE(rays_alive && out && n_out, "compact_alive: null pointer");
     NGP_REQUIRE(workspace && workspace_bytes >= ngp_compact_alive_workspace(n_alive), "compact_alive: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const uint32_t nblocks = ngp_div_up(n_alive ? n_alive : 1, RM_BLOCK);
     uint32_t* block_sums = (uint32_t*)workspace;
     hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums);
-    hipLaunchKernelGGL(k_compact_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums, out, n_out);
+    hipLaunchKernelGGL(k_compact_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums, out, n_out, host_pair, seq);
     NGP_CHECK_LAUNCH("compact_alive");
+    return NGP_OK;
+}
+
+extern "C" int ngp_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    return rm_compact_alive(rays_alive, n_alive, out, n_out, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+// The same, and the count also goes to the HOST without a stream synchronisation: host_pair = two int32 of pinned, device-visible, coherent memory
+// (ngp_host_words_alloc); the kernel stores the count in [0] and then `seq` in [1] (system scope, release): a caller that needs the number to shape its
+// next tensors (the inference loop, nerf/renderer.py:365, once per iteration) polls [1] for its sequence number instead of paying an interrupt-driven
+// hipStreamSynchronize + a 4-byte copy per iteration.  What is launched next on the stream is ordered behind the compaction as always.
+extern "C" int ngp_compact_alive_publish(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out, int32_t* host_pair, int32_t seq,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    NGP_REQUIRE(host_pair, "compact_alive_publish: null host words");
+    return rm_compact_alive(rays_alive, n_alive, out, n_out, host_pair, seq, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ngp_host_words_alloc(uint32_t n_words, void** host_ptr) {
+    NGP_REQUIRE(host_ptr && n_words >= 1 && n_words <= 4096, "host_words_alloc: 1 .. 4096 words");
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)n_words * 4, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !p)
+        return ngp_fail(NGP_ELAUNCH, "host_words_alloc: hipHostMalloc failed");
+    memset(p, 0, (size_t)n_words * 4);
+    *host_ptr = p;
+    return NGP_OK;
+}
+extern "C" int ngp_host_words_free(void* host_ptr) {
+    if (host_ptr && hipHostFree(host_ptr) != hipSuccess) return ngp_fail(NGP_ELAUNCH, "host_words_free: hipHostFree failed");
     return NGP_OK;
 }

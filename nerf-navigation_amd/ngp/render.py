@@ -215,10 +215,10 @@ class NGPRenderer(nn.Module):
                 raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
                 if trace is not None:
                     trace.append((n_alive, n_step, int((deltas[:, 0] > 0).sum().item())))
-                # stable compaction on the device; one 4-byte readback for the new count (the reference's boolean mask
-                # costs the same sync, nerf/renderer.py:365)
-                packed, cnt = raymarching.compact_alive(rays_alive, n_alive)
-                rays_alive = packed[: int(cnt.item())]
+                # stable compaction on the device; the new count reaches the host through two pinned words the kernel writes (no stream synchronisation:
+                # the reference's boolean mask, nerf/renderer.py:365, pays one + a copy per iteration)
+                packed, _, kept = raymarching.compact_alive(rays_alive, n_alive, count=True)
+                rays_alive = packed[:kept]
                 step += n_step
             image, depth = mix_background(weights_sum, depth, image, nears, fars, bg_color)
             results["weights_sum"] = weights_sum

@@ -49,6 +49,9 @@ _SIGNATURES = {
     "ngp_composite_rays_half": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ngp_compact_alive_workspace": (c_sz, [c_u32]),
     "ngp_compact_alive": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "ngp_compact_alive_publish": (c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "ngp_host_words_alloc": (c_int, [c_u32, c_vp]),
+    "ngp_host_words_free": (c_int, [c_vp]),
     "ngp_density_grid_points": (c_u32, [c_u32, c_u32, c_int]),
     "ngp_density_grid_workspace": (c_sz, [c_u32, c_u32]),
     "ngp_density_grid_sample": (c_int, [c_vp, c_u32, c_u32, c_f32, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_sz, c_vp]),

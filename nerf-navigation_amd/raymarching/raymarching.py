@@ -6,7 +6,9 @@ behaviour as the reference (file:line cited per function).  Differences, all sup
   * kernels run on torch's current HIP stream (the reference used the legacy default stream);
   * march_rays_train allocates slots in ray order (deterministic) instead of atomic arrival order.
 """
+import ctypes
 import functools
+import time
 
 import torch
 from torch.autograd import Function
@@ -285,14 +287,44 @@ class _composite_rays(Function):
 composite_rays = _public(_composite_rays)
 
 
-def compact_alive(rays_alive, n_alive=None):
+_HOST_PAIRS = {}          # device index -> [ctypes int32 pair in pinned coherent memory, device address, last sequence number]
+
+
+def _host_pair(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    entry = _HOST_PAIRS.get(key)
+    if entry is None:
+        p = ctypes.c_void_p()
+        _hip.check(_hip.lib().ngp_host_words_alloc(2, ctypes.byref(p)), "host_words_alloc")
+        entry = _HOST_PAIRS[key] = [(ctypes.c_int32 * 2).from_address(p.value), p, 0]
+    return entry
+
+
+def compact_alive(rays_alive, n_alive=None, count=False):
     """Stable compaction `rays_alive[rays_alive >= 0]` (nerf/renderer.py:365) done on the device.
-    Returns (compacted [n_alive] int32, count [1] int32 device tensor); only the first count entries are valid."""
+    Returns (compacted [n_alive] int32, count [1] int32 device tensor); only the first count entries are valid.
+    count=True: also the count as a Python int, third, WITHOUT a stream synchronisation -- the kernel stores it in two pinned words the host polls
+    (ngp_compact_alive_publish); the reference's boolean-mask indexing pays a synchronisation + copy here, once per iteration of the inference loop."""
     n = rays_alive.shape[0] if n_alive is None else n_alive
     out = torch.empty(max(n, 1), dtype=torch.int32, device=rays_alive.device)
     cnt = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
     L = _hip.lib()
     ws = _hip.workspace(L.ngp_compact_alive_workspace(n), rays_alive.device)
-    _hip.check(L.ngp_compact_alive(_hip.ptr(rays_alive), n, _hip.ptr(out), _hip.ptr(cnt), _hip.ptr(ws), ws.numel(), _hip.stream()),
-               "compact_alive")
-    return out, cnt
+    if not count:
+        _hip.check(L.ngp_compact_alive(_hip.ptr(rays_alive), n, _hip.ptr(out), _hip.ptr(cnt), _hip.ptr(ws), ws.numel(), _hip.stream()),
+                   "compact_alive")
+        return out, cnt
+    entry = _host_pair(rays_alive.device)
+    pair, seq = entry[0], (entry[2] % 0x7FFFFFF0) + 1
+    entry[2] = seq
+    _hip.check(L.ngp_compact_alive_publish(_hip.ptr(rays_alive), n, _hip.ptr(out), _hip.ptr(cnt), entry[1], seq, _hip.ptr(ws), ws.numel(), _hip.stream()),
+               "compact_alive_publish")
+    spins, deadline = 0, None
+    while pair[1] != seq:
+        spins += 1
+        if spins & 0xFFF == 0:                      # (a launch that never ran must not hang the caller: after 5 s fall back to the synchronising read)
+            now = time.perf_counter()
+            deadline = deadline or now + 5.0
+            if now > deadline:
+                return out, cnt, int(cnt.item())
+    return out, cnt, int(pair[0])

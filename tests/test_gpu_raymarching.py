@@ -344,6 +344,23 @@ def _composite_rays_train_forward_backward(oracle, dev, scene, density):
     assert_same_bits(tc.grad, gc_r, "grad_rgbs")
 
 
+def test_compact_alive_hands_the_count_to_the_host_without_a_synchronisation(dev):
+    """compact_alive(count=True): the kernel stores the count in pinned words the host polls (ngp_compact_alive_publish); the same list and count as the
+    synchronising form, call after call (the sequence number tells one call's count from the previous one's)"""
+    import raymarching
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 64, 1000, 70001, 640000, 5):
+        a = rng.integers(-1, 50, size=n).astype(np.int32)
+        a[rng.random(n) < 0.5] = -1
+        ta = t(a, dev)
+        packed, cnt, k = raymarching.compact_alive(ta, n, count=True)
+        want = a[a >= 0]
+        assert k == want.size == int(cnt.item())
+        assert np.array_equal(packed[:k].cpu().numpy(), want)
+    packed, cnt, k = raymarching.compact_alive(torch.full((300,), -1, dtype=torch.int32, device=dev), 300, count=True)
+    assert k == 0
+
+
 def test_empty_inputs(dev):
     import raymarching
     z3 = torch.zeros(0, 3, device=dev)
