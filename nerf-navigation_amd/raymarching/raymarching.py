@@ -8,6 +8,7 @@ behaviour as the reference (file:line cited per function).  Differences, all sup
 """
 import ctypes
 import functools
+import threading
 import time
 
 import torch
@@ -296,7 +297,7 @@ def _host_pair(device):
     if entry is None:
         p = ctypes.c_void_p()
         _hip.check(_hip.lib().ngp_host_words_alloc(2, ctypes.byref(p)), "host_words_alloc")
-        entry = _HOST_PAIRS[key] = [(ctypes.c_int32 * 2).from_address(p.value), p, 0]
+        entry = _HOST_PAIRS[key] = [(ctypes.c_int32 * 2).from_address(p.value), p, 0, threading.Lock()]
     return entry
 
 
@@ -315,16 +316,17 @@ def compact_alive(rays_alive, n_alive=None, count=False):
                    "compact_alive")
         return out, cnt
     entry = _host_pair(rays_alive.device)
-    pair, seq = entry[0], (entry[2] % 0x7FFFFFF0) + 1
-    entry[2] = seq
-    _hip.check(L.ngp_compact_alive_publish(_hip.ptr(rays_alive), n, _hip.ptr(out), _hip.ptr(cnt), entry[1], seq, _hip.ptr(ws), ws.numel(), _hip.stream()),
-               "compact_alive_publish")
-    spins, deadline = 0, None
-    while pair[1] != seq:
-        spins += 1
-        if spins & 0xFFF == 0:                      # (a launch that never ran must not hang the caller: after 5 s fall back to the synchronising read)
-            now = time.perf_counter()
-            deadline = deadline or now + 5.0
-            if now > deadline:
-                return out, cnt, int(cnt.item())
-    return out, cnt, int(pair[0])
+    with entry[3]:                                  # one pair per device: a second thread's call waits for this one's count
+        pair, seq = entry[0], (entry[2] % 0x7FFFFFF0) + 1
+        entry[2] = seq
+        _hip.check(L.ngp_compact_alive_publish(_hip.ptr(rays_alive), n, _hip.ptr(out), _hip.ptr(cnt), entry[1], seq, _hip.ptr(ws), ws.numel(), _hip.stream()),
+                   "compact_alive_publish")
+        spins, deadline = 0, None
+        while pair[1] != seq:
+            spins += 1
+            if spins & 0xFFF == 0:                  # (a launch that never ran must not hang the caller: after 5 s fall back to the synchronising read)
+                now = time.perf_counter()
+                deadline = deadline or now + 5.0
+                if now > deadline:
+                    return out, cnt, int(cnt.item())
+        return out, cnt, int(pair[0])
