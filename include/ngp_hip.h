@@ -96,6 +96,10 @@ int ngp_march_rays_train_filled(const float* rays_o, const float* rays_d, const 
  * every mode; returns the previous setting. */
 int ngp_march_set_wave_per_ray(int enabled);   /* also selects the wave-per-ray kernels of ngp_composite_rays_train_* */
 int ngp_composite_set_scan(int enabled);       /* wave-per-ray compositors: chains as lane scans (1, default) or every lane running the recurrence (0); returns the previous setting */
+/* Validation switch, process-wide, default 1: the inference march (ngp_march_rays, ngp_march_rays_fill with a workspace) stops a ray where it leaves the box of everything occupied
+ * in the grid -- formed per call from the coarse map, when the cascades nest in powers of two -- instead of walking on to its far through cells that are all empty.
+ * Same samples either way; returns the previous setting. */
+int ngp_march_set_occupied_box(int enabled);
 
 /* raymarching.h:14 composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
 int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
@@ -440,6 +444,9 @@ size_t ngp_render_frame_workspace(uint32_t N);
  * grid when that provably visits the reference's samples (render_fused.hip, rv_probe).  0 = march cell by cell like
  * kernel_march_rays (raymarching.cu:748-801).  Results are identical either way; returns the previous setting. */
 int ngp_render_set_block_skip(int enabled);
+/* Validation switch, process-wide, default 1: a ray of ngp_render_frame marches no further than where it leaves the box of everything occupied in the
+ * grid (beyond it every cell is empty: the reference tests those cells and finds nothing).  0 = to its own far.  Results are identical; returns the previous setting. */
+int ngp_render_set_occupied_box(int enabled);
 int ngp_render_frame(const ngp_field_t* field_host, const float* rays_o, const float* rays_d, uint32_t N,
                      uint32_t image_width, const float* aabb, float min_near, const uint8_t* bitfield, uint32_t C, uint32_t Hgrid,
                      float dt_gamma, uint32_t max_steps, const float* bg_color3_host,

@@ -153,6 +153,45 @@ __device__ __forceinline__ float ngp_skip_margin(const V& r, float bound, float 
     return 4.8e-7f * (pos * rd + fabsf(far));           // 8 * 2^-24 = 4.8e-7
 }
 
+// ---------------------------------------------------------------------------
+// The box of everything occupied (round 4).  Beyond it every cell of the grid is empty: the reference tests those cells and finds nothing, so a march that
+// stops a little behind the box produces the same samples -- and a ray does not walk out of the scene through dozens of empty probes (46 empty probes per ray
+// in the 800x800 frame, most of them behind the last sample: profiles/HISTORY.md 4.1).  The extent is kept on one integer lattice for all cascades: unit = a
+// 4^3 block of cascade 0, origin = the low corner of the outermost cascade; cascade l: a block is 2^l units and its box starts (2^(C-1) - 2^l) nb / 2 units in
+// (nb = blocks per axis) -- exact when the cascades nest in powers of two, the condition of the verified skips (ngp_skip_allowed).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ngp_unmorton(uint32_t v) {          // every third bit of a Morton index, packed
+    v &= 0x09249249u;
+    v = (v | (v >> 2)) & 0x030C30C3u;
+    v = (v | (v >> 4)) & 0x0300F00Fu;
+    v = (v | (v >> 8)) & 0x030000FFu;
+    v = (v | (v >> 16)) & 0x000003FFu;
+    return v;
+}
+
+// word = 32 coarse bits = the Morton blocks [32 wi, 32 wi + 32) of cascade `level`: an aligned group of 4 x 4 x 2 blocks (bit i: x = bits 0, 3 of i, y = bits 1, 4,
+// z = bit 2).  Widens lo / hi (lattice units) by the set blocks of the word; no loop over the bits.
+__device__ __forceinline__ void ngp_occ_extent_word(uint32_t word, uint32_t wi, uint32_t level, uint32_t C, uint32_t nb, uint32_t (&lo)[3], uint32_t (&hi)[3]) {
+    if (!word) return;
+    const uint32_t m = wi * 32u;
+    const uint32_t base[3] = {ngp_unmorton(m), ngp_unmorton(m >> 1), ngp_unmorton(m >> 2)};
+    const uint32_t X[4] = {0x00550055u, 0x00AA00AAu, 0x55005500u, 0xAA00AA00u}, Y[4] = {0x00003333u, 0x0000CCCCu, 0x33330000u, 0xCCCC0000u};
+    uint32_t mn[3], mx[3];
+    mn[0] = (word & X[0]) ? 0u : (word & X[1]) ? 1u : (word & X[2]) ? 2u : 3u;
+    mx[0] = (word & X[3]) ? 3u : (word & X[2]) ? 2u : (word & X[1]) ? 1u : 0u;
+    mn[1] = (word & Y[0]) ? 0u : (word & Y[1]) ? 1u : (word & Y[2]) ? 2u : 3u;
+    mx[1] = (word & Y[3]) ? 3u : (word & Y[2]) ? 2u : (word & Y[1]) ? 1u : 0u;
+    mn[2] = (word & 0x0F0F0F0Fu) ? 0u : 1u;
+    mx[2] = (word & 0xF0F0F0F0u) ? 1u : 0u;
+    const uint32_t off = (((1u << (C - 1u)) - (1u << level)) * nb) >> 1;
+    #pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t p = off + ((base[k] + mn[k]) << level), q = off + ((base[k] + mx[k] + 1u) << level);
+        lo[k] = p < lo[k] ? p : lo[k];
+        hi[k] = q > hi[k] ? q : hi[k];
+    }
+}
+
 // Whether block skipping is exact for a grid: blocks must align with the cascade boundaries (cells H/4 and 3H/4 of the next
 // level) and every level's half-width must be a power of two; the reference's binary32 cell index must be exact.
 __host__ __device__ inline bool ngp_skip_allowed(uint32_t C, uint32_t H, float bound) {

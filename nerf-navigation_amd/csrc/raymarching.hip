@@ -162,6 +162,7 @@ struct march_args {
     uint32_t max_steps, N, C, H, M, perturb;
     const uint32_t* coarse = nullptr;   // optional coarse occupancy map (global; the kernels stage it in LDS), one bit per 4^3 block
     uint32_t coarse_words = 0;         // 32-bit words per cascade level (H^3 / 64 / 32)
+    const float* occ = nullptr;        // optional: the box of everything occupied (k_rm_occupied_box: lo[3], hi[3], pad), where a ray's march may stop
 };
 
 // coarse bit b = any cell of Morton block b (64 cells = one aligned 64-bit word of the bitfield) is occupied.  One lane per block word, the
@@ -178,6 +179,10 @@ __global__ __launch_bounds__(RM_BLOCK) void k_rm_build_coarse(const uint8_t* __r
 }
 
 static constexpr size_t RM_COARSE_MAX = 48 * 1024;                     // largest map the march kernels stage in LDS (H = 128: 4 KiB per cascade)
+static constexpr size_t RM_OCC_BYTES = 64;                             // behind the map in the workspace: the occupied box, 7 floats
+// validation switch (process-wide, default 1): the per-op march kernels stop a ray where it leaves the box of everything occupied; 0 = at its own far
+static std::atomic<int> rm_occ_box_enabled{1};
+extern "C" int ngp_march_set_occupied_box(int enabled) { return rm_occ_box_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 // bytes of the coarse map for this grid, or 0 when it is not used (cell index not exact in binary32, H^3 / 64 not a multiple of 32,
 // misaligned bitfield, or too large for LDS): exactly the condition under which ngp_march_t caches 64-bit block words
@@ -188,15 +193,61 @@ static size_t rm_coarse_bytes(const uint8_t* grid, uint32_t C, uint32_t H) {
     return bytes <= RM_COARSE_MAX ? bytes : 0;
 }
 
+// The box of everything occupied, from the coarse map, once per march call (one workgroup): the extent of the set blocks of all cascades on one integer
+// lattice (ngp_march.h: ngp_occ_extent_word), reduced with LDS atomics, written in world coordinates one unit wider on every side, + box[6] = how far behind the box a
+// march may still look (two of the largest steps).  Beyond that box every cell is empty: the reference tests those cells and finds nothing, so a march that
+// stops there produces the same samples.  Needs the cascades nested in powers of two: the condition of the verified block skips (ngp_skip_allowed).
+__global__ __launch_bounds__(1024) void k_rm_occupied_box(const uint32_t* __restrict__ coarse, uint32_t coarse_words, uint32_t C, uint32_t H, float top, float unit,
+                                                          float* __restrict__ box) {
+    __shared__ uint32_t s_ext[6];
+    if (threadIdx.x < 6) s_ext[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t nw = C * coarse_words, blocks_per_level = coarse_words * 32u;
+    uint32_t nb = 1;
+    while (nb * nb * nb < blocks_per_level) nb <<= 1;
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = threadIdx.x; i < nw; i += 1024u) {
+        const uint32_t level = i / coarse_words;
+        ngp_occ_extent_word(coarse[i], i - level * coarse_words, level, C, nb, lo, hi);
+    }
+    if (hi[0]) {
+        #pragma unroll
+        for (int k = 0; k < 3; k++) { atomicMax(s_ext + k, (1u << 20) - lo[k]); atomicMax(s_ext + 3 + k, hi[k]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t k = threadIdx.x;
+        const bool any = s_ext[3] != 0u;                               // nothing occupied: an empty box far away, every ray misses it
+        box[k] = any ? -top + ((float)((1u << 20) - s_ext[k]) - 1.0f) * unit : 3.0e38f;
+        box[3 + k] = any ? -top + ((float)s_ext[3 + k] + 1.0f) * unit : 3.1e38f;
+        if (k == 0) box[6] = 2.0f * (((2.0f * 1.7320508075688772f) * (float)(1u << (C - 1u))) / (float)H);
+    }
+}
+
 // builds the map into `dst` (device) and points the march arguments at it
-static void rm_attach_coarse(march_args& a, void* dst, hipStream_t s) {
+static void rm_attach_coarse(march_args& a, void* dst, hipStream_t s, bool with_box) {
     const uint32_t n_blocks_total = a.C * (a.H * a.H * a.H / 64);
     hipLaunchKernelGGL(k_rm_build_coarse, dim3(ngp_div_up(n_blocks_total, RM_BLOCK)), dim3(RM_BLOCK), 0, s, a.grid, n_blocks_total, (uint32_t*)dst);
     a.coarse = (const uint32_t*)dst;
     a.coarse_words = a.H * a.H * a.H / 64 / 32;
+    // the occupied box (behind the map, RM_OCC_BYTES): one more small launch per call
+    if (with_box && rm_occ_box_enabled.load(std::memory_order_relaxed) && ngp_skip_allowed(a.C, a.H, a.bound)) {
+        float* box = reinterpret_cast<float*>(static_cast<unsigned char*>(dst) + (size_t)a.C * a.coarse_words * 4);
+        hipLaunchKernelGGL(k_rm_occupied_box, dim3(1), dim3(1024), 0, s, a.coarse, a.coarse_words, a.C, a.H, a.C == 1u ? a.bound : (float)(1u << (a.C - 1u)),
+                           2.0f * (a.C == 1u ? a.bound : 1.0f) / (float)(a.H / 4u), box);
+        a.occ = box;
+    }
 }
 
 // every thread of a RM_RAY_BLOCK workgroup calls this before marching: copies the map into dynamic LDS (or returns nullptr without one)
+// where the march of ray (o, d) may stop: its own far, or a little behind the occupied box (-inf when it misses the box: nothing to march)
+__device__ __forceinline__ float rm_march_far(const float* box, const float* o, const float* d, float far) {
+    if (!box) return far;
+    float n2, f2;
+    ngp_near_far_inline(o, d, box, 0.0f, n2, f2);
+    return f2 == 3.402823466e+38f ? -__builtin_inff() : fminf(far, f2 + box[6]);
+}
+
 template <uint32_t BLOCK = RM_RAY_BLOCK>
 __device__ __forceinline__ const uint32_t* rm_stage_coarse(const march_args& a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t rm_lds_coarse[];
@@ -244,14 +295,15 @@ __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count(march_args a
                                                                 uint32_t* __restrict__ block_sums, float* __restrict__ tbuf) {
     __shared__ uint32_t lds4[RM_RAY_BLOCK / 64];
     const uint32_t* lds_coarse = rm_stage_coarse(a);
+    const float* occ = a.occ;
     const uint32_t n = blockIdx.x * RM_RAY_BLOCK + threadIdx.x;
     uint32_t num_steps = 0;
     if (n < a.N) {
         ngp_march_t m;
         m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
         m.use_coarse(lds_coarse, a.coarse_words);
-        const float far = a.fars[n];
-        m.allow_skip(a.C, a.H, far);
+        const float far = rm_march_far(occ, a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.fars[n]);
+        m.allow_skip(a.C, a.H, occ ? far + 4.0f * a.bound : far);
         float t = train_t0(m, a.nears[n], n, a.perturb), x, y, z, dt;
         float* tb = tbuf ? tbuf + (size_t)n * a.max_steps : nullptr;
         while (t < far && num_steps < a.max_steps) {
@@ -390,12 +442,14 @@ __device__ __forceinline__ uint32_t rm_wave_march(const ngp_march_t& m, const ui
 __global__ __launch_bounds__(RM_RAY_BLOCK) void k_march_train_count_wave(march_args a, int* __restrict__ rays, const int* __restrict__ counter,
                                                                      float* __restrict__ tbuf, uint32_t replay_only) {
     const uint32_t* lds_coarse = rm_stage_coarse(a);
+    const float* occ = a.occ;
     const uint32_t n = blockIdx.x;
     const int lane = (int)threadIdx.x;
     ngp_march_t m;
     m.setup(a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.bound, a.dt_gamma, a.max_steps, a.C, a.H, a.grid);
     float* tb = tbuf + (size_t)n * a.max_steps;
-    const uint32_t count = rm_wave_march(m, lds_coarse, a.coarse_words, train_t0(m, a.nears[n], n, a.perturb), a.fars[n], a.max_steps, replay_only != 0u,
+    const float far = rm_march_far(occ, a.rays_o + 3ull * n, a.rays_d + 3ull * n, a.fars[n]);     // (windows behind the occupied box hold no sample)
+    const uint32_t count = rm_wave_march(m, lds_coarse, a.coarse_words, train_t0(m, a.nears[n], n, a.perturb), far, a.max_steps, replay_only != 0u,
                                          [&](uint32_t found, unsigned long long smask, float tk, float) {
         if ((smask >> lane) & 1ull) tb[found + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull))] = tk;    // the samples' parameters, in order
     });
@@ -595,7 +649,7 @@ extern "C" int ngp_march_set_wave_per_ray(int enabled) { return rm_wave_march_en
 static size_t rm_train_ws_base(uint32_t N) { return (sizeof(uint32_t) * ((size_t)ngp_div_up(N ? N : 1, RM_RAY_BLOCK) + 4) + 255) & ~(size_t)255; }
 
 // block sums and bases | room for a coarse occupancy map (built per call: the bitfield changes every 16 steps)
-extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) { return rm_train_ws_base(N) + RM_COARSE_MAX; }
+extern "C" size_t ngp_march_rays_train_workspace(uint32_t N) { return rm_train_ws_base(N) + RM_COARSE_MAX + RM_OCC_BYTES; }
 
 // The same plus room for every sample's t (N * max_steps floats): with it the second pass does not march again.
 extern "C" size_t ngp_march_rays_train_workspace_full(uint32_t N, uint32_t max_steps) {
@@ -629,7 +683,9 @@ static int rm_march_rays_train(const float* rays_o, const float* rays_d, const u
     if (workspace_bytes >= ngp_march_rays_train_workspace_full(N, max_steps))
         tbuf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + ngp_march_rays_train_workspace(N));
     const size_t cbytes = rm_coarse_bytes(grid, C, H);
-    if (cbytes) rm_attach_coarse(a, reinterpret_cast<unsigned char*>(workspace) + rm_train_ws_base(N), s);
+    // (no occupied box for the training march: a training batch's rays mostly end inside the learned grid's box, the wave-per-ray count pass crosses what is
+    //  left in 64-point windows, and the extra launch and per-ray slab test cost more than they save: 0.872 against 0.846 ms per step, measured)
+    if (cbytes) rm_attach_coarse(a, reinterpret_cast<unsigned char*>(workspace) + rm_train_ws_base(N), s, false);
     // one wave per ray when the lattice is closed-form (constant step) and the sample parameters can be recorded; else one lane per ray
     const int wave_mode = rm_wave_march_enabled.load(std::memory_order_relaxed);
     const bool wave_per_ray = tbuf && cbytes && dt_gamma == 0.0f && C <= 4 && wave_mode != 0;
@@ -1101,6 +1157,7 @@ __global__ __launch_bounds__(BLOCK) void k_march_rays(uint32_t n_alive, uint32_t
                                                          float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
     // reference: raymarching.cu:707-814
     const uint32_t* lds_coarse = rm_stage_coarse<BLOCK>(a);
+    const float* occ = a.occ;
     const uint32_t n = blockIdx.x * BLOCK + threadIdx.x;
     if (FILL) {
         // a.M rows in all; rows past the last ray's slots are spread over the launch's lanes
@@ -1120,8 +1177,10 @@ __global__ __launch_bounds__(BLOCK) void k_march_rays(uint32_t n_alive, uint32_t
     float* pd = dirs + 3ull * n * n_step;
     float* pl = deltas + 2ull * n * n_step;
     float t = rays_t[index];
-    const float far = a.fars[index];
-    m.allow_skip(a.C, a.H, far);
+    // (a ray that has left the box of everything occupied has no sample left: it ends here, not after walking to its far through empty cells -- the walk that
+    //  set the duration of every late call of the inference loop, profiles/HISTORY.md 4.4)
+    const float far = rm_march_far(occ, a.rays_o + 3ll * index, a.rays_d + 3ll * index, a.fars[index]);
+    m.allow_skip(a.C, a.H, occ ? far + 4.0f * a.bound : far);
     if (a.perturb) {                                  // seed = perturb, jump = alive SLOT (reference :752-755,819)
         ngp_pcg32 rng; rng.seed((uint64_t)a.perturb);
         rng.advance((uint64_t)n);
@@ -1198,8 +1257,8 @@ static int march_rays_launch(bool fill, uint32_t M, uint32_t n_alive, uint32_t n
     // the coarse map pays when rays cross empty space; it is rebuilt on every call (2 us: the bitfield may have changed, and a cache
     // keyed on a pointer could go stale silently)
     const size_t cbytes = (workspace && n_alive) ? rm_coarse_bytes(grid, C, H) : 0;
-    const size_t lds = (cbytes && workspace_bytes >= cbytes) ? cbytes : 0;
-    if (lds) rm_attach_coarse(a, workspace, (hipStream_t)stream);
+    const size_t lds = (cbytes && workspace_bytes >= cbytes + RM_OCC_BYTES) ? cbytes : 0;
+    if (lds) rm_attach_coarse(a, workspace, (hipStream_t)stream, true);
     const bool big = n_alive >= 65536u;          // (measured: the frame takes the same time with 64-thread workgroups throughout; 256 stage the map 4x less often)
     const uint32_t bs = big ? RM_BLOCK : RM_RAY_BLOCK;
     const dim3 grid_dim(ngp_div_up(n_alive ? n_alive : 1, bs)), block(bs);
@@ -1229,7 +1288,7 @@ extern "C" int ngp_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int3
                              xyzs, dirs, deltas, perturb, workspace, workspace_bytes, stream);
 }
 
-extern "C" size_t ngp_march_rays_workspace(uint32_t C, uint32_t H) { (void)C; (void)H; return RM_COARSE_MAX; }
+extern "C" size_t ngp_march_rays_workspace(uint32_t C, uint32_t H) { (void)C; (void)H; return RM_COARSE_MAX + RM_OCC_BYTES; }
 
 extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
                                   const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {

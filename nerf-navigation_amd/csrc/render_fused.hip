@@ -162,12 +162,17 @@ struct rf_frame {
     uint32_t coarse_words;           // words per cascade level
     uint32_t tile_w;                 // image width in pixels when the rays are a row-major image (8x8 tile order), else 0
     uint32_t skip;                   // 1: empty 4^3 / 16^3 blocks may be skipped (rv_probe); decided on the host from H, C, bound
+    const uint32_t* occ_ext;         // the extent of the occupied blocks (k_build_coarse), or null: a ray marches no further than where it leaves that box
+    float occ_unit, occ_top;         // world size of one unit of that lattice, and the half-width of the outermost cascade (its origin is -occ_top)
     const uint32_t* tile_order;      // [N/64] 8x8 tiles, most expensive first (k_tile_order), or null
 };
 
 // coarse[level][m] = any fine bit set in Morton block m (64 bits = 8 bytes of the bitfield)
+// coarse[level][m] = any fine bit set in Morton block m (64 bits = 8 bytes of the bitfield).
+// ext (optional, 6 words, zeroed by the caller): the extent of the occupied blocks of ALL cascades on one integer lattice (ngp_march.h: ngp_occ_extent_word)
+// as [2^20 - lo] x 3 (atomicMax of an inverted minimum) and [hi] x 3; hi == 0: nothing is occupied.
 __global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict__ bitfield, uint32_t n_blocks_total,
-                                                      uint32_t* __restrict__ coarse) {
+                                                      uint32_t* __restrict__ coarse, uint32_t blocks_per_level, uint32_t C, uint32_t* __restrict__ ext) {
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;                 // one 32-bit word of coarse bits per thread
     if (w * 32 >= n_blocks_total) return;
     const uint64_t* b64 = reinterpret_cast<const uint64_t*>(bitfield);
@@ -178,6 +183,15 @@ __global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict_
         if (blk < n_blocks_total && b64[blk] != 0ull) bits |= 1u << i;
     }
     coarse[w] = bits;
+    if (ext && bits) {
+        uint32_t nb = 1;                                               // blocks per axis
+        while (nb * nb * nb < blocks_per_level) nb <<= 1;
+        uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+        const uint32_t words_per_level = blocks_per_level / 32u, level = w / words_per_level;
+        ngp_occ_extent_word(bits, w - level * words_per_level, level, C, nb, lo, hi);
+        #pragma unroll
+        for (int k = 0; k < 3; k++) { atomicMax(ext + k, (1u << 20) - lo[k]); atomicMax(ext + 3 + k, hi[k]); }
+    }
 }
 
 // The march state of ngp_march_t split in two so that only what differs per ray occupies VGPRs:
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
 template <bool FIXED>
 __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame& F, const rf_iter_class cls_rt,
                                               const ngp_h8* __restrict__ lds_w, _Float16* lds_sh, const rf_lane_levels* lds_lv,
-                                              float4* lds_smp, const uint32_t* lds_coarse, unsigned long long* lds_chunk) {
+                                              float4* lds_smp, const uint32_t* lds_coarse, unsigned long long* lds_chunk, const float* lds_occ) {
     const rf_iter_class cls = FIXED ? rf_iter_class{1u, 12u, 2u} : cls_rt;
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15, wave = threadIdx.x >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the same, known to be uniform
@@ -756,6 +770,13 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                             ngp_camera_ray(F.cam, ray, d);
                         }
                         ngp_near_far_inline(o, d, F.aabb, F.min_near, near, far);
+                        if (lds_occ) {
+                            // `far` is from here on where the MARCH stops: no later than a little behind the box of everything occupied (beyond it every
+                            // cell is empty: the reference would test and find nothing).  The ray's own far is formed again when the ray retires.
+                            float n2, f2;
+                            ngp_near_far_inline(o, d, lds_occ, 0.0f, n2, f2);
+                            far = f2 == 3.402823466e+38f ? near : fminf(far, f2 + lds_occ[6]);
+                        }
                         m.ox = o[0]; m.oy = o[1]; m.oz = o[2];
                         m.dx = d[0]; m.dy = d[1]; m.dz = d[2];
                         m.rdx = 1.0f / m.dx; m.rdy = 1.0f / m.dy; m.rdz = 1.0f / m.dz;
@@ -808,7 +829,9 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
             // vector registers; a copy per round keeps every memory access out of the probe loop
             rv_consts Kr = K;
             asm("" : "+v"(Kr.Hf), "+v"(Kr.Hm1), "+v"(Kr.Cf), "+v"(Kr.rH), "+v"(Kr.dt_min), "+v"(Kr.dt_max), "+v"(Kr.rbound), "+v"(Kr.H3));
-            const float M = (active && F.skip) ? ngp_skip_margin(mr, K.bound, far_r) : __builtin_inff();
+            // (the margin bounds rounding errors by the largest ray parameter in play: the march limit may have been pulled in to the occupied box, the
+            //  points a skip evaluates lie at most one cascade further)
+            const float M = (active && F.skip) ? ngp_skip_margin(mr, K.bound, lds_occ ? far_r + 4.0f * K.bound : far_r) : __builtin_inff();
             // this lane's slots, recomputed from the lane id (2 VALU) rather than kept across the field evaluation in scratch
             const uint32_t slot0 = ((uint32_t)wave_s * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) * RV_S;
             float4* const smp_w = lds_smp + slot0;
@@ -1036,13 +1059,19 @@ __device__ __forceinline__ void rv_frame_loop(const rf_params& P, const rf_frame
                 break;
             }
         }
-        const bool capped = !done && ended && nsamp >= F.max_steps && t < far;
+        float far0 = far;                                   // the ray's own far (the depth map's scale, the cap statistic): formed again, once per ray
+        if (lds_occ && (done || ended)) {
+            const float o3[3] = {m.ox, m.oy, m.oz}, d3[3] = {m.dx, m.dy, m.dz};
+            float n0;
+            ngp_near_far_inline(o3, d3, F.aabb, F.min_near, n0, far0);
+        }
+        const bool capped = !done && ended && nsamp >= F.max_steps && t < far0;
         if (ended) done = true;
         if (done) {
             F.image[3ull * ray] = cr + (1 - ws) * F.bg[0];
             F.image[3ull * ray + 1] = cg + (1 - ws) * F.bg[1];
             F.image[3ull * ray + 2] = cb + (1 - ws) * F.bg[2];
-            F.depth[ray] = fmaxf(dacc - near, 0.0f) / (far - near);
+            F.depth[ray] = fmaxf(dacc - near, 0.0f) / (far0 - near);
             F.weights_sum[ray] = ws;
             n_capped_local += capped ? 1u : 0u;        // counted per lane, added to F.stats once when the wave retires
             n_hit_local += nsamp > 0 ? 1u : 0u;
@@ -1112,6 +1141,17 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
         const uint32_t nw = F.coarse_words * F.C;
         for (uint32_t i = threadIdx.x; i < nw; i += RV_BLOCK) lds_coarse[i] = F.coarse[i];
     }
+    // the box of everything occupied, in world units, one unit (a 4^3 block of cascade 0) wider on every side than the blocks say, + how far behind it a march may
+    // still look (two of the largest steps): 7 floats behind the coarse map
+    float* lds_occ = (lds_coarse && F.occ_ext) ? reinterpret_cast<float*>(lds_coarse + F.coarse_words * F.C) : nullptr;
+    if (lds_occ && threadIdx.x < 3) {
+        const uint32_t k = threadIdx.x;
+        const uint32_t hi = F.occ_ext[3 + k], lo = (1u << 20) - F.occ_ext[k];
+        const bool any = F.occ_ext[3] != 0u;                       // nothing occupied at all: an empty box far away, every ray misses it
+        lds_occ[k] = any ? -F.occ_top + ((float)lo - 1.0f) * F.occ_unit : 3.0e38f;
+        lds_occ[3 + k] = any ? -F.occ_top + ((float)hi + 1.0f) * F.occ_unit : 3.1e38f;
+        if (k == 0) lds_occ[6] = 2.0f * (((2.0f * 1.7320508075688772f) * (float)(1 << (F.C - 1))) / (float)F.H);
+    }
     if (wave == 0 && s == 0) {
         rf_lane_levels tmp;
         rf_setup_levels(P, g, tmp);
@@ -1120,15 +1160,18 @@ __global__ __launch_bounds__(RV_BLOCK, RV_WAVES_PER_SIMD) void k_render_frame_mu
     __syncthreads();
     const rf_iter_class cls = rf_classify(lds_lv[g]);
     if (cls.dense == 1u && cls.select == 2u && cls.hashed == 12u)
-        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse, rv_chunk_p);
+        rv_frame_loop<true>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse, rv_chunk_p, lds_occ);
     else
-        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse, rv_chunk_p);
+        rv_frame_loop<false>(P, F, cls, lds_w, lds_sh, lds_lv, lds_smp, lds_coarse, rv_chunk_p, lds_occ);
 }
 #endif  // RV_S > 1
 
 static inline bool rv_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
 // process-wide validation switch; atomic because callers may render from several host threads (one stream each)
+static std::atomic<int> rv_occ_box_enabled{1};
+// validation switch: 0 = every ray marches to its own far (as before round 4); results are identical either way
+extern "C" int ngp_render_set_occupied_box(int enabled) { return rv_occ_box_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> rv_block_skip_enabled{1};
 extern "C" int ngp_render_set_block_skip(int enabled) { return rv_block_skip_enabled.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
@@ -1200,7 +1243,7 @@ static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, c
     if (hint >= 8 && hint % 8 == 0 && N % hint == 0 && (N / hint) % 8 == 0) F.tile_w = hint;
 
     // coarse occupancy (needs Morton blocks: H a power of two >= 4) in the workspace, then in LDS
-    F.coarse = nullptr; F.coarse_words = 0; F.skip = 0;
+    F.coarse = nullptr; F.coarse_words = 0; F.skip = 0; F.occ_ext = nullptr; F.occ_unit = 0.0f; F.occ_top = 0.0f;
     static_assert(sizeof(rf_lane_levels) * 4 == RV_LDS_LV, "LDS carve of the level table");
     size_t lds = RV_LDS_W + RV_LDS_SH + RV_LDS_LV;
 #if RV_S > 1
@@ -1218,10 +1261,24 @@ static int rv_render_frame(const ngp_field_t* field_host, const float* rays_o, c
         workspace_bytes >= RV_WS_COARSE + coarse_bytes && (reinterpret_cast<uintptr_t>(bitfield) & 7u) == 0) {
         uint32_t* coarse = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + RV_WS_COARSE);
         const uint32_t n_blocks_total = (uint32_t)(C * blocks_per_level);
-        hipLaunchKernelGGL(k_build_coarse, dim3(ngp_div_up(n_blocks_total / 32, 256)), dim3(256), 0, s, bitfield, n_blocks_total, coarse);
         F.coarse = coarse;
         F.coarse_words = (uint32_t)(blocks_per_level / 32);
         lds += coarse_bytes;
+        // block skipping and the occupied box need the cascades nested in powers of two (see below)
+        uint32_t* ext = nullptr;
+#if RV_S > 1
+        int e2;
+        const bool nested = Hgrid >= 64 && (C == 1 || frexpf(field_host->bound, &e2) == 0.5f);
+        if (nested && rv_occ_box_enabled.load(std::memory_order_relaxed) && lds + 32 <= 160 * 1024) {
+            ext = reinterpret_cast<uint32_t*>(workspace) + 26;          // header words 26..31 (zeroed above)
+            F.occ_ext = ext;
+            F.occ_top = C == 1 ? field_host->bound : (float)(1u << (C - 1));
+            F.occ_unit = 2.0f * (C == 1 ? field_host->bound : 1.0f) / (float)(Hgrid / 4);
+            lds += 32;
+        }
+#endif
+        hipLaunchKernelGGL(k_build_coarse, dim3(ngp_div_up(n_blocks_total / 32, 256)), dim3(256), 0, s, bitfield, n_blocks_total, coarse,
+                           (uint32_t)blocks_per_level, C, ext);
         // block skipping needs the 16^3 blocks aligned with the cascade boundaries (cells H/4 and 3H/4 of the next level) and
         // every level's half-width a power of two: H a power of two >= 64, and bound a power of two unless there is one cascade
         int e;

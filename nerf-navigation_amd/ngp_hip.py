@@ -38,6 +38,7 @@ _SIGNATURES = {
                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_sz, c_vp]),
     "ngp_march_set_wave_per_ray": (c_int, [c_int]),
     "ngp_composite_set_scan": (c_int, [c_int]),
+    "ngp_march_set_occupied_box": (c_int, [c_int]),
     "ngp_composite_rays_train_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp]),
     "ngp_composite_rays_train_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp]),
     "ngp_march_rays": (c_int, [c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
@@ -97,6 +98,7 @@ _SIGNATURES = {
     "ngp_field_train_live_list": (c_int, [c_vp, c_u32, c_vp, c_vp]),
     "ngp_render_frame_workspace": (c_sz, [c_u32]),
     "ngp_render_set_block_skip": (c_int, [c_int]),
+    "ngp_render_set_occupied_box": (c_int, [c_int]),
     "ngp_field_train_set_two_pass": (c_int, [c_int]),
     "ngp_field_train_set_live_only": (c_int, [c_int]),
     "ngp_render_frame": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_f32, c_vp, c_u32, c_u32, c_f32, c_u32, c_vp,
@@ -220,6 +222,9 @@ def lib():
         _lib = _GuardedLib(handle)
         if os.environ.get("NGP_FT_TWO_PASS") in ("0", "1"):              # A/B switch of the training forward (tools, bench.py --mode train); default: two passes
             handle.ngp_field_train_set_two_pass(int(os.environ["NGP_FT_TWO_PASS"]))
+        if os.environ.get("NGP_OCC_BOX") in ("0", "1"):                  # ... of the march limit at the occupied box (frame kernel and per-op march kernels)
+            handle.ngp_render_set_occupied_box(int(os.environ["NGP_OCC_BOX"]))
+            handle.ngp_march_set_occupied_box(int(os.environ["NGP_OCC_BOX"]))
         if os.environ.get("NGP_FT_LIVE_ONLY") in ("0", "1"):             # ... of the training backward (live samples only | all samples)
             handle.ngp_field_train_set_live_only(int(os.environ["NGP_FT_LIVE_ONLY"]))
     return _lib

@@ -182,6 +182,53 @@ def test_block_skipping_changes_nothing(full, oracle, dev, scene, dt_gamma, pose
     assert torch.equal(a["image"], b["image"]) and torch.equal(a["stats"][:3], b["stats"][:3])
 
 
+@pytest.mark.parametrize("scene,dt_gamma,pose", [("sring", 0.0, 1), ("sring", 1.0 / 128, 5), ("blobs", 0.0, 3), ("blobs", 1.0 / 256, 6), ("corner", 0.0, 2),
+                                                 ("empty", 0.0, 0), ("full", 0.0, 4)])
+def test_the_occupied_box_changes_nothing(full, oracle, dev, scene, dt_gamma, pose):
+    """A ray of the fused kernel marches no further than where it leaves the box of everything occupied in the grid (render_fused.hip: k_build_coarse's extent,
+    the refill's second slab test); beyond that box the reference tests empty cells only.  Switch off = every ray to its own far.  640,000 rays, a constant
+    small density (every sample counts, nothing saturates) and the real field: bit-identical images, depths, weights and statistics -- on the ring, on scattered
+    blobs, on one small off-centre blob (most rays miss the box), on an empty grid and on a full one (the box is the whole volume)."""
+    import ngp_hip
+    W = full["W"]
+    if scene in ("sring", "blobs"):
+        grid = _scene_grid(W, oracle, scene)
+    else:
+        grid = np.zeros_like(_scene_grid(W, oracle, "sring"))
+        if scene == "full":
+            grid[:] = 1.0
+        elif scene == "corner":
+            g = grid.reshape(2, -1)
+            idx = oracle.morton3D(np.stack(np.meshgrid(np.arange(100, 110), np.arange(56, 70), np.arange(58, 71), indexing="ij"), -1).reshape(-1, 3).astype(np.int32))
+            g[0, idx] = 1.0
+    ren = _constant_density_renderer(dev, grid, 1e-3)
+    o, d = W.get_rays(W.orbit_pose(pose), W.intrinsics(RES, RES), RES, RES)
+    o, d = t(o, dev), t(d, dev)
+    L = ngp_hip.lib()
+    outs = {}
+    for mode in (0, 1):
+        previous = L.ngp_render_set_occupied_box(mode)
+        try:
+            outs[mode] = (ren.render_fused(o[None], d[None], bg_color=1, dt_gamma=dt_gamma, image_width=RES),
+                          full["ren"].render_fused(o[None], d[None], bg_color=1, dt_gamma=dt_gamma, image_width=RES) if scene == "sring" else None)
+            torch.cuda.synchronize()
+        finally:
+            L.ngp_render_set_occupied_box(previous)
+    for a, b in zip(outs[0], outs[1]):
+        if a is None:
+            continue
+        assert torch.equal(a["stats"][:3], b["stats"][:3])
+        for key in ("weights_sum", "depth", "image"):
+            assert torch.equal(a[key], b[key]), f"{key}: {int((a[key] != b[key]).sum())} values differ"
+    st = outs[1][0]["stats"].cpu().numpy()
+    if scene == "empty":
+        assert st[0] == 0
+    elif scene == "corner":
+        assert 0 < st[0] < 3_000_000
+    else:
+        assert st[0] > 5_000_000
+
+
 @pytest.mark.parametrize("scene,pose", [("sring", 2), ("blobs", 4)])
 def test_fused_march_gives_every_ray_the_single_march_sample_count(full, oracle, dev, scene, pose):
     """Constant density, constant step (dt_gamma 0), no saturation: a ray's weights_sum depends on its sample count alone

@@ -361,6 +361,46 @@ def test_compact_alive_hands_the_count_to_the_host_without_a_synchronisation(dev
     assert k == 0
 
 
+@pytest.mark.parametrize("kind", ["blobs", "empty", "full"])
+def test_the_occupied_box_changes_no_sample(oracle, dev, kind):
+    """the inference march stops a ray where it leaves the box of everything occupied (formed per call from the coarse map): with the switch on and off, and
+    against the oracle (which walks every ray to its far), the same samples (the training march, which does not use the box, beside it) -- a sparse grid, an
+    empty and a full one"""
+    import ngp_hip
+    import raymarching
+    bound, cas, grid_h = 2.0, 2, 128
+    bf, _ = blob_bitfield(oracle, cas, grid_h, seed=11, n_blobs=3, bound=bound)
+    if kind == "empty":
+        bf = np.zeros_like(bf)
+    elif kind == "full":
+        bf = np.full_like(bf, 0xFF)
+    o, d = camera_rays(40, radius=3.0, seed=4)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    N = o.shape[0]
+    alive = np.arange(N, dtype=np.int32)
+    x_ref, _, l_ref = oracle.march_rays(N, 8, alive, nears.copy(), o, d, bound, bf, cas, grid_h, nears, fars, 128, False, 0.0, 1024)
+    ref = oracle.march_rays_train(o, d, bound, bf, cas, grid_h, nears, fars, force_all_rays=True, dt_gamma=0.0, max_steps=256)
+    for mode in (1, 0):
+        previous = ngp_hip.lib().ngp_march_set_occupied_box(mode)
+        try:
+            x, _, l = raymarching.march_rays(N, 8, t(alive, dev), t(nears, dev), t(o, dev), t(d, dev), bound, t(bf, dev), cas, grid_h, t(nears, dev), t(fars, dev),
+                                             128, False, 0.0, 1024)
+            counter = torch.zeros(2, dtype=torch.int32, device=dev)
+            xt, _, lt, rays = raymarching.march_rays_train(t(o, dev), t(d, dev), bound, t(bf, dev), cas, grid_h, t(nears, dev), t(fars, dev), counter, -1, False, 128,
+                                                           True, 0.0, 256)
+        finally:
+            ngp_hip.lib().ngp_march_set_occupied_box(previous)
+        assert_same_bits(x, x_ref, f"xyzs mode {mode}")
+        assert_same_bits(l, l_ref, f"deltas mode {mode}")
+        total = int(counter[0].item())
+        assert total == int(ref[3][:, 2].sum())
+        assert_same_bits(rays, ref[3], f"rays mode {mode}")
+        assert_same_bits(xt[:total], ref[0][:total], f"train xyzs mode {mode}")
+        assert_same_bits(lt[:total], ref[2][:total], f"train deltas mode {mode}")
+    assert (kind == "empty") == (not (l_ref[:, 0] > 0).any())
+
+
 def test_empty_inputs(dev):
     import raymarching
     z3 = torch.zeros(0, 3, device=dev)
